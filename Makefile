@@ -1,0 +1,31 @@
+# Builds the GPU library, the C host layer around it, the command-line renderer and the test oracle.
+#   make            -> raytracer_amd/librtgpu.so, raytracer_amd/librthost.so, raytracer_amd/raytrace
+#   make oracle     -> oracle/liboracle.so (+ oracle/_ref/ref_dump when /root/reference is present)
+HIPCC   ?= hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG     := raytracer_amd
+# -ffp-contract=off: the trace path must round exactly like the reference's non-FMA binary32 code.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC
+CFLAGS   := -O2 -std=gnu99 -ffp-contract=off -fPIC -Wall
+HOSTSRC  := $(PKG)/host/scene.c $(PKG)/host/bitmap.c $(PKG)/host/raytrace.c $(PKG)/host/error.c
+
+all: $(PKG)/librtgpu.so $(PKG)/librthost.so $(PKG)/raytrace
+
+$(PKG)/librtgpu.so: $(PKG)/csrc/rtgpu.hip $(wildcard $(PKG)/csrc/*.h) include/rtgpu.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+$(PKG)/librthost.so: $(HOSTSRC) $(PKG)/host/rt_host.h include/rtgpu.h $(PKG)/librtgpu.so
+	$(CC) $(CFLAGS) -shared -o $@ $(HOSTSRC) -L$(PKG) -lrtgpu -Wl,-rpath,'$$ORIGIN' -lm
+
+$(PKG)/raytrace: $(PKG)/host/main.c $(PKG)/librthost.so
+	$(CC) $(CFLAGS) -o $@ $< -L$(PKG) -lrthost -lrtgpu -Wl,-rpath,'$$ORIGIN' -lm
+
+oracle:
+	$(MAKE) -C oracle oracle
+	if [ -d /root/reference/src ]; then $(MAKE) -C oracle ref; fi
+
+clean:
+	rm -f $(PKG)/librtgpu.so $(PKG)/librthost.so $(PKG)/raytrace
+
+.PHONY: all oracle clean

@@ -1,0 +1,173 @@
+/* rtgpu — C ABI of the MI355X (gfx950) implementation of the per-pixel trace path.
+ *
+ * This is the drop-in boundary.  The reference renders a frame with one call,
+ *     RT_VisualizedScene* rtVisualizedSceneRaytrace(RT_Scene*, RT_Camera*)   (src/raytrace.h:57)
+ * followed by rtVisualizedSceneToBitmap (src/raytrace.h:64).  A host that keeps the reference's
+ * loaders and BMP writer replaces the body of those two functions with the calls below (the stub is
+ * shown in INTEGRATION.md; raytracer_amd/host/raytrace.c is a complete host built that way).
+ *
+ * Only plain-old-data crosses this boundary: counts, float/int arrays, opaque handle.  Every function
+ * returns 0 on success or an RTGPU_E_* code; the codes 1..7 are the reference's errno values
+ * (src/error.h:19-42) so the C caller can store them into errno unchanged.
+ *
+ * Pointers named d_* are DEVICE pointers (hipMalloc'd by the caller, e.g. a torch tensor's data_ptr);
+ * all other pointers are host memory.  One context drives one GPU; contexts are not thread-safe.
+ */
+#ifndef RTGPU_H
+#define RTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTGPU_OK 0
+#define RTGPU_E_IO 1               /* E_IO */
+#define RTGPU_E_MEMORY 2           /* E_MEMORY */
+#define RTGPU_E_NOT_ENOUGH_SURFACES 6 /* E_NOT_ENOUGH_SURFACES (src/scene.c:291-294) */
+#define RTGPU_E_INVALID_PARAM 7    /* E_INVALID_PARAM_VALUE (src/voxelize.c:169-191) */
+#define RTGPU_E_NO_DEVICE 100      /* no HIP device / HIP runtime error */
+#define RTGPU_E_STATE 101          /* call order violated (e.g. render before frame_begin) */
+#define RTGPU_E_UNSUPPORTED 102    /* combination the GPU path does not implement (see message) */
+
+typedef struct rtgpu_ctx rtgpu_ctx;
+
+/* RT_Surface (src/scene.h:32-36) without the unused alpha lane. */
+typedef struct rtgpu_surface {
+  float color[3];
+  float kd, ks, g, ka, kt, eta, kr;
+} rtgpu_surface;
+
+/* RT_Light (src/scene.h:59-63). */
+typedef struct rtgpu_light {
+  float p[3];
+  float flux;
+  float color[3];
+} rtgpu_light;
+
+/* RT_PlanarLight (src/scene.h:67-73): origin a and the edge vectors ab, ac computed by the loader
+ * (src/scene.c:496-498). */
+typedef struct rtgpu_planar_light {
+  float flux;
+  float color[3];
+  float a[3], ab[3], ac[3];
+} rtgpu_planar_light;
+
+/* RT_Camera (src/scene.h:109-113). */
+typedef struct rtgpu_camera {
+  float ob[3], ul[3], bl[3], ur[3];
+  int32_t sw, sh;
+} rtgpu_camera;
+
+/* What rtSceneLoad / rtSceneSet* leave in RT_Scene (src/scene.h:88-105), flattened. */
+typedef struct rtgpu_scene_desc {
+  int32_t nt, ns, nl, npl;
+  const float *vertices;            /* nt*9: i, j, k of each triangle AFTER the loader's vertex nudge (src/scene.c:138-181) */
+  const int32_t *sid;               /* nt surface ids */
+  const rtgpu_surface *surfaces;    /* ns */
+  const rtgpu_light *lights;        /* nl (may be NULL when nl == 0) */
+  const rtgpu_planar_light *planar; /* npl (may be NULL when npl == 0) */
+  float dmin[3], dmax[3];           /* RT_Scene.dmin/dmax as the loader left them */
+  float gamma, distmod;             /* RT_SceneConfig (src/scene.h:77-83) */
+  int32_t vmode;                    /* 0 VOX_DEFAULT, 1 VOX_MODIFIED_DEFAULT, 2 VOX_FIXED */
+  float vcoeff[3];
+  int32_t texture_present;          /* 1 if "textures/brickwall.bmp" could be loaded (src/preprocess.c:13) */
+} rtgpu_scene_desc;
+
+/* Grid geometry of the current frame (RT_Udd, src/voxelize.h:21-25, plus the grown domain). */
+typedef struct rtgpu_grid_info {
+  int32_t nv[3];
+  float cell[3];
+  float dmin[3], dmax[3];
+  int32_t ncells;
+  int32_t nrefs;       /* total triangle references over all cells */
+  float total_flux;    /* src/raytrace.c:346-348 */
+} rtgpu_grid_info;
+
+/* Ray statistics of the last rtgpu_render call, counted the way SURVEY/BASELINE define "rays":
+ * nearest-hit queries + shadow queries as the reference issues them. */
+typedef struct rtgpu_counters {
+  int64_t pixels;          /* pixels of this rank's tiles inside the image */
+  int64_t pixels_traced;   /* ... whose primary ray entered the grid */
+  int64_t nearest_queries; /* rtUddFindNearestTriangle calls (src/voxelize.c:536) */
+  int64_t shadow_queries;  /* rtUddFindShadow calls (src/voxelize.c:615), back-face early-outs included */
+  int64_t shadow_walks;    /* shadow queries that reached the grid walk */
+  int64_t nearest_steps, nearest_tests; /* S and T of the nearest walks (only with option "count" = 1) */
+  int64_t shadow_steps, shadow_tests;   /* S and T of the shadow walks   (only with option "count" = 1) */
+} rtgpu_counters;
+
+/* Per-kernel device time of the last rtgpu_frame_begin + rtgpu_render, from HIP events on the
+ * context's stream (only with option "timing" = 1; the events serialise the kernels). */
+typedef struct rtgpu_timings {
+  float preprocess_ms, grid_ms, primary_ms, nearest_ms, hit_ms, shadow_ms, accumulate_ms, minmax_ms;
+  int32_t nearest_launches, shadow_launches;
+} rtgpu_timings;
+
+const char *rtgpu_error_string(int code);
+/* Text of the last failure on this context (HIP error text, unsupported combination, ...). */
+const char *rtgpu_last_message(const rtgpu_ctx *ctx);
+
+/* Creates a context on HIP device `device` and its stream.  Fails with RTGPU_E_NO_DEVICE when there
+ * is no usable GPU: there is no CPU fallback. */
+int rtgpu_create(int device, rtgpu_ctx **out);
+void rtgpu_destroy(rtgpu_ctx *ctx);
+
+/* Options: "count" (0/1) S/T counters, "timing" (0/1) per-kernel events, "chunk_bytes" (device
+ * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size). */
+int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);
+
+/* Copies the scene to the GPU (replaces RT_Scene as the renderer's input). */
+int rtgpu_scene_upload(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
+
+/* Everything rtVisualizedSceneRaytrace does before its pixel loop (src/raytrace.c:341-366):
+ * per-triangle preprocess for this camera (src/preprocess.c:17-38), light-driven domain growth,
+ * grid dimensions (rtUddCreate) and the grid build (rtUddVoxelize), all from the pristine scene:
+ * unlike the reference (which mutates RT_Scene.dmin/dmax) this call is idempotent. */
+int rtgpu_frame_begin(rtgpu_ctx *ctx, const rtgpu_camera *cam);
+int rtgpu_grid_info_get(const rtgpu_ctx *ctx, rtgpu_grid_info *out);
+
+/* Image tiling.  The image is cut into 8x8-pixel tiles, numbered row-major; rank r of `world`
+ * owns tiles r, r+world, r+2*world, ...  Tile-major buffers hold 64 pixels per owned tile (pixel
+ * (x,y) of a tile at slot (y&7)*8 + (x&7)); slots outside the image are padding. */
+int64_t rtgpu_tile_count(const rtgpu_ctx *ctx, int rank, int world);
+
+/* The pixel loop (src/raytrace.c:371-404) for the tiles of `rank`.
+ *   d_rgb    : tile_count*64*3 floats, raw colour (RT_VisualizedScenePixel.c), 0 where the reference leaves the pixel unwritten
+ *   d_ids    : tile_count*64 int32, index of the primary-hit triangle (RT_VisualizedScenePixel.t - scene->t) or -1
+ *   d_minmax : 6 floats, min r,g,b then max r,g,b over this rank's traced pixels (src/raytrace.c:396-399),
+ *              initialised to FLT_MAX / FLT_MIN like src/raytrace.c:317-320
+ * Asynchronous on the context's stream; rtgpu_sync waits. */
+int rtgpu_render(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax);
+
+/* rtVisualizedSceneToBitmap's per-pixel map (src/raytrace.c:433-466) on n pixels in any order:
+ * rgba = R<<24 | G<<16 | B<<8 (src/bitmap.h:70) of trunc(pow((c-min)*delta, gamma)*255).
+ * d_minmax holds the GLOBAL min/max (after the exchange between ranks). */
+int rtgpu_tonemap(rtgpu_ctx *ctx, const float *d_rgb, int64_t npixels, const float *d_minmax, float gamma,
+                  uint32_t *d_rgba);
+
+/* De-interleaves tile-major data gathered from all ranks (rank r's block first, each block
+ * rtgpu_tile_count(r)*64 elements of elem_bytes) into a row-major w*h image. */
+int rtgpu_untile(rtgpu_ctx *ctx, const void *d_gathered, int world, int elem_bytes, void *d_image);
+
+int rtgpu_sync(rtgpu_ctx *ctx);
+int rtgpu_counters_get(rtgpu_ctx *ctx, rtgpu_counters *out);
+int rtgpu_timings_get(rtgpu_ctx *ctx, rtgpu_timings *out);
+
+/* Single-GPU convenience for a C host: frame_begin must have been called; renders all tiles and
+ * returns row-major host arrays (rgb w*h*3, ids w*h, minmax 6).  Any output may be NULL. */
+int rtgpu_render_host(rtgpu_ctx *ctx, float *rgb, int32_t *ids, float *minmax);
+/* Host-array form of rtgpu_tonemap (row-major in, row-major out). */
+int rtgpu_tonemap_host(rtgpu_ctx *ctx, const float *rgb, int64_t npixels, const float *minmax, float gamma,
+                       uint32_t *rgba);
+
+/* Introspection used by the parity tests: grid lists (cell_start: ncells+1, refs: nrefs, ascending
+ * triangle index inside a cell as src/voxelize.c:252-283 inserts them) and the per-triangle
+ * preprocess results (n[3], ij[3], ik[3], d : 10 floats per triangle, src/preprocess.c:19-32). */
+int rtgpu_grid_download(rtgpu_ctx *ctx, int32_t *cell_start, int32_t *refs);
+int rtgpu_triangles_download(rtgpu_ctx *ctx, float *out10);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGPU_H */

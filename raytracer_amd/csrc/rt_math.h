@@ -1,0 +1,174 @@
+// Device arithmetic of the trace path.
+//
+// The reference is strict IEEE binary32 with no fused multiply-add, except for a handful of spots
+// where C's promotion rules make it compute in double; a flipped last bit in any geometric predicate
+// changes which triangle a ray hits.  Every helper here therefore spells out the reference's
+// operation order (file:line under /root/reference/src) and the file is compiled with
+// -ffp-contract=off, correctly rounded division/sqrt and denormals preserved.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+#include "rt_types.h"
+
+#define RT_D __device__ __forceinline__
+
+namespace rt {
+
+RT_D f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_D f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+RT_D void st3(float *p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+RT_D f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_D f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_D f3 mul3(f3 a, float t) { return mk3(a.x * t, a.y * t, a.z * t); }
+RT_D f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+
+// vectormath.h:95-97: (a0*b0 + a1*b1) + a2*b2
+RT_D float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// vectormath.h:87-92
+RT_D f3 cross3(f3 a, f3 b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// vectormath.h:60-66: `1.0f/sqrt(float)` promotes to double: sqrt and the division are binary64, the
+// quotient is rounded to float once.
+RT_D f3 normalize3(f3 v) {
+  float s = v.x * v.x + v.y * v.y + v.z * v.z;
+  float inv = (float)(1.0 / sqrt((double)s));
+  return mk3(v.x * inv, v.y * inv, v.z * inv);
+}
+// vectormath.h:122-127: normalised b - a
+RT_D f3 ray3(f3 a, f3 b) { return normalize3(sub3(b, a)); }
+// vectormath.h:45-48: sqrt evaluated in double, result rounded to float
+RT_D float dist3(f3 a, f3 b) {
+  float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return (float)sqrt((double)(dx * dx + dy * dy + dz * dz));
+}
+// vectormath.h:131-136: o + d*r
+RT_D f3 raypoint3(f3 o, f3 r, float d) { return mk3(o.x + d * r.x, o.y + d * r.y, o.z + d * r.z); }
+// vectormath.h:144-159: normalize((2*n)*ndl - l)
+RT_D f3 reflect3(f3 n, f3 l, float ndl) {
+  return normalize3(mk3(2.0f * n.x * ndl - l.x, 2.0f * n.y * ndl - l.y, 2.0f * n.z * ndl - l.z));
+}
+// vectormath.h:162-169: the sqrt is binary64 and so is the subtraction it feeds; f is rounded once.
+// Total internal reflection gives sqrt(<0) = NaN and an all-NaN direction, exactly as on the CPU.
+RT_D f3 refract3(f3 n, f3 l, float eta) {
+  float ndl = dot3(n, l);
+  float arg = 1.0f - (eta * eta) * (1.0f - ndl * ndl);
+  float f = (float)((double)(eta * ndl) - sqrt((double)arg));
+  return normalize3(mk3(f * n.x - eta * l.x, f * n.y - eta * l.y, f * n.z - eta * l.z));
+}
+
+RT_D float absf_ref(float x) { return x >= 0.0f ? x : -x; }  // common.h:27
+// common.h:35 MIN(a,b,c) with its exact comparison structure (matters when a NaN is involved)
+RT_D float min3_ref(float a, float b, float c) {
+  float ab = a < b ? a : b;
+  return c < ab ? c : ab;
+}
+RT_D int min3i(int a, int b, int c) { int ab = a < b ? a : b; return c < ab ? c : ab; }
+RT_D int max3i(int a, int b, int c) { int ab = a > b ? a : b; return c > ab ? c : ab; }
+
+// float -> int32 the way the reference binary does it (x86-64 cvttss2si): truncation, and INT_MIN for
+// NaN or out-of-range input.  The GPU conversion saturates and maps NaN to 0, which would put a NaN
+// point INSIDE voxel 0.
+RT_D int f2i_x86(float x) {
+  return (x > -2147483904.0f && x < 2147483648.0f) ? (int)x : INT_MIN;
+}
+
+// voxelize.h:32-43
+RT_D bool voxel_of(const GridP &g, f3 p, int &i, int &j, int &k) {
+  i = f2i_x86((p.x - g.dmin[0]) / g.cs[0]);
+  j = f2i_x86((p.y - g.dmin[1]) / g.cs[1]);
+  k = f2i_x86((p.z - g.dmin[2]) / g.cs[2]);
+  if (i < 0 || i >= g.nv[0]) return false;
+  if (j < 0 || j >= g.nv[1]) return false;
+  if (k < 0 || k >= g.nv[2]) return false;
+  return true;
+}
+// voxelize.h:47-49
+RT_D int cell_index(const GridP &g, int i, int j, int k) { return (i * g.nv[1] + j) * g.nv[2] + k; }
+
+// voxelize.c:417-471
+RT_D bool startup_voxel(const GridP &g, f3 o, f3 r, int &i, int &j, int &k) {
+  if (voxel_of(g, o, i, j, k)) return true;
+  float d1 = FLT_MAX, d2 = FLT_MAX;
+  const float oo[3] = {o.x, o.y, o.z}, rr[3] = {r.x, r.y, r.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (rr[a] != 0.0f) {
+      float d = (g.dmin[a] - oo[a]) / rr[a];
+      if (d > 0.0f) {
+        if (d < d1) { d2 = d1; d1 = d; } else if (d < d2) d2 = d;
+      }
+      d = (g.dmax[a] - oo[a]) / rr[a];
+      if (d > 0.0f) {
+        if (d < d1) { d2 = d1; d1 = d; } else if (d < d2) d2 = d;
+      }
+    }
+  }
+  if (voxel_of(g, raypoint3(o, r, d1), i, j, k)) return true;
+  if (voxel_of(g, raypoint3(o, r, d2), i, j, k)) return true;
+  return false;
+}
+
+// 3D-DDA state (voxelize.c:56-121).  tx/ty/tz are ACCUMULATED sums exactly like the reference's.
+struct Dda {
+  float tx, ty, tz, dtx, dty, dtz;
+  int i, j, k;
+  int di, dj, dk;
+};
+
+RT_D void dda_axis(float lo, float cs, int idx, float o, float r, float &dt, float &t, int &step) {
+  float p1 = lo + idx * cs;
+  float p2 = p1 + cs;
+  if (r == 0.0f) {
+    dt = FLT_MAX;
+    t = 0.0f;
+  } else {
+    float t1 = (p1 - o) / r;
+    float t2 = (p2 - o) / r;
+    dt = absf_ref(t2 - t1);
+    t = t1 < t2 ? t1 : t2;
+  }
+  step = r > 0.0f ? 1 : -1;
+}
+RT_D void dda_init(const GridP &g, f3 o, f3 r, int i, int j, int k, Dda &w) {
+  w.i = i; w.j = j; w.k = k;
+  dda_axis(g.dmin[0], g.cs[0], i, o.x, r.x, w.dtx, w.tx, w.di);
+  dda_axis(g.dmin[1], g.cs[1], j, o.y, r.y, w.dty, w.ty, w.dj);
+  dda_axis(g.dmin[2], g.cs[2], k, o.z, r.z, w.dtz, w.tz, w.dk);
+}
+// voxelize.c:594-606 (ties go to the later axis)
+RT_D void dda_step(Dda &w) {
+  float xn = w.tx + w.dtx, yn = w.ty + w.dty, zn = w.tz + w.dtz;
+  if (xn < yn) {
+    if (xn < zn) { w.i += w.di; w.tx = xn; } else { w.k += w.dk; w.tz = zn; }
+  } else {
+    if (yn < zn) { w.j += w.dj; w.ty = yn; } else { w.k += w.dk; w.tz = zn; }
+  }
+}
+
+// Möller–Trumbore exactly as intersection.c:58-86 evaluates it.
+RT_D bool tri_test(f3 a, f3 ab, f3 ac, f3 o, f3 r, float &d, float &u, float &v) {
+  f3 p = cross3(r, ac);
+  float det = dot3(ab, p);
+  if (det > -0.000001f && det < 0.000001f) return false;
+  float inv = 1.0f / det;
+  f3 tv = sub3(o, a);
+  u = dot3(tv, p) * inv;
+  if (u < 0.0f || u > 1.0f) return false;
+  f3 q = cross3(tv, ab);
+  v = dot3(r, q) * inv;
+  if (v < 0.0f || u + v > 1.0f) return false;
+  d = dot3(ac, q) * inv;
+  if (d < 0.0f) return false;
+  return true;
+}
+
+// float -> uint32_t as the reference binary converts the tone-mapped channel (64-bit cvttss2si, low
+// half kept): NaN and out-of-range give 0, negatives wrap.
+RT_D uint32_t f2u_x86(float x) {
+  if (!(x > -9223373136366403584.0f && x < 9223372036854775808.0f)) return 0u;
+  return (uint32_t)(unsigned long long)(long long)x;
+}
+
+}  // namespace rt

@@ -1,0 +1,97 @@
+// Plain-old-data records shared by the HIP kernels and the host side of librtgpu.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+constexpr int kTile = 8;          // image tiles are 8x8 pixels = one wavefront of primary rays
+constexpr int kTilePixels = 64;
+constexpr int kMaxLevels = 5;     // recursion depth of the reference (src/raytrace.c:390)
+constexpr int kPlanarSamples = 16; // src/raytrace.c:242
+
+struct f3 { float x, y, z; };
+
+// One triangle reference of a grid cell, self-contained so that a cell's list is a linear stream:
+// vertex i and the edges ij, ik (all that src/intersection.c:58-86 reads), the triangle index and the
+// transparency kt of its surface (what the shadow walk needs, src/voxelize.c:703).
+struct __attribute__((aligned(16))) TriRec {
+  float a[3];
+  float ab[3];
+  float ac[3];
+  int32_t id;
+  float kt;
+  int32_t pad;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec is 48 bytes");
+
+// Uniform grid ("UDD", src/voxelize.h:21-25) plus the grown scene domain.
+struct GridP {
+  float dmin[3], dmax[3], cs[3];
+  int32_t nv[3];
+  int32_t ncells;
+  const uint32_t *cell_start;  // ncells+1 offsets into cell_tris
+  const TriRec *cell_tris;
+};
+
+// A ray waiting for its nearest-hit walk.  i < 0 marks a lane without work:
+// -1 = primary ray that never enters the grid (src/raytrace.c:381-382), -2 = padding outside the image.
+struct __attribute__((aligned(16))) Ray {
+  float o[3];
+  float r[3];
+  int32_t i, j, k;   // start voxel
+  int32_t current;   // triangle the ray leaves (excluded by identity, src/voxelize.c:574), -1 for primary rays
+  int32_t pad[2];
+};
+static_assert(sizeof(Ray) == 48, "Ray is 48 bytes");
+
+// Result of a nearest-hit walk (src/voxelize.c:583-590).
+struct __attribute__((aligned(16))) Hit {
+  int32_t tri;       // >= 0 triangle, -1 miss, -2 no ray
+  float d, u, v;
+  int32_t i, j, k;   // voxel the hit was found in: start voxel of the secondary rays (src/raytrace.c:195)
+  int32_t pad;
+};
+static_assert(sizeof(Hit) == 32, "Hit is 32 bytes");
+
+// A shaded hit: everything the light loops of src/raytrace.c:211-296 need.
+struct __attribute__((aligned(16))) Node {
+  float p[3];        // onew, the hit point
+  float n[3];        // shading normal (flipped towards the ray, bump-mapped)
+  float c[3];        // nc, surface or texture colour
+  int32_t tri;       // >= 0 triangle, -1 miss, -2 no ray
+  int32_t refl;      // global node index of the reflected child or -1
+  int32_t refr;      // global node index of the refracted child or -1
+};
+static_assert(sizeof(Node) == 48, "Node is 48 bytes");
+
+struct SurfaceD { float color[3]; float kd, ks, g, ka, kt, eta, kr; };
+struct LightD { float p[3]; float flux; float color[3]; };
+struct PlanarD { float flux; float color[3]; float a[3], ab[3], ac[3]; };
+
+struct CameraD { float ob[3], ul[3], bl[3], ur[3]; int32_t sw, sh; };
+
+// Scene-wide constants handed to the shading kernels.
+struct ShadeP {
+  const SurfaceD *surf;
+  const LightD *lights;
+  const PlanarD *planar;
+  const float *tri_aux;     // per triangle n[3], d
+  const int32_t *tri_sid;
+  const int32_t *rand_tab;  // glibc rand() stream for the planar-light replay, or nullptr
+  int32_t nl, npl, nslots;  // nslots = nl + 16*npl shadow queries per shaded hit
+  int32_t tex_tri[4];       // triangles carrying the brick texture (src/preprocess.c:45-71), -1 = none
+  float total_flux, distmod;
+};
+
+// Device-side control block of one chunk: queue lengths, tickets of the persistent kernels, statistics.
+struct Ctl {
+  int32_t count[kMaxLevels + 1];        // rays/nodes per level
+  uint32_t ticket_nearest[kMaxLevels];
+  uint32_t ticket_shadow[kMaxLevels];
+  uint32_t pad;
+  unsigned long long stat[16];
+};
+enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
+            kNearLaneTests, kNearWaveTests, kShaded, kStatCount };
+
+}  // namespace rt

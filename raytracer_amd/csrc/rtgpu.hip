@@ -1,0 +1,630 @@
+// librtgpu: host side of the C ABI declared in include/rtgpu.h.
+// Owns the device copies of the scene, the per-frame grid and the ray/node queues of a chunk, and
+// sequences the kernels of rt_kernels.h on one HIP stream.  There is no CPU rendering path here:
+// without a HIP device rtgpu_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtgpu.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+namespace {
+
+struct TimedSpan { hipEvent_t a, b; int what; };
+enum What { W_PRE = 0, W_GRID, W_PRIMARY, W_NEAREST, W_HIT, W_SHADOW, W_ACCUM, W_MINMAX, W_COUNT };
+
+}  // namespace
+
+struct rtgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+  std::string msg;
+  // options
+  bool opt_count = false, opt_timing = false;
+  int64_t chunk_bytes = 8ll << 30;
+  int waves_per_cu = 32;
+  // scene, host side
+  bool have_scene = false, have_frame = false;
+  int nt = 0, ns = 0, nl = 0, npl = 0;
+  std::vector<rtgpu_light> lights;
+  std::vector<rtgpu_surface> surfaces;
+  float dmin0[3], dmax0[3], gamma = 2.5f, distmod = 2.0f, vcoeff[3] = {0, 0, 0};
+  int vmode = 0, texture_present = 0;
+  int tex_tri[4] = {-1, -1, -1, -1};
+  int fan = 0, levels = 1;
+  // scene, device side
+  float *d_verts = nullptr, *d_geom = nullptr, *d_aux = nullptr;
+  int32_t *d_sid = nullptr, *d_box = nullptr, *d_refs = nullptr, *d_rand = nullptr;
+  SurfaceD *d_surf = nullptr;
+  LightD *d_lights = nullptr;
+  PlanarD *d_planar = nullptr;
+  uint32_t *d_counts = nullptr, *d_cell_start = nullptr;
+  TriRec *d_recs = nullptr;
+  size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
+  // frame
+  CameraD cam = {};
+  GridP grid = {};
+  rtgpu_grid_info ginfo = {};
+  ShadeP shade = {};
+  // chunk queues
+  size_t chunk_tiles_cap = 0;
+  size_t cap[kMaxLevels] = {0, 0, 0, 0, 0}, base[kMaxLevels] = {0, 0, 0, 0, 0}, total_nodes = 0;
+  Ray *d_rays[kMaxLevels] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  Hit *d_hits = nullptr;  // sized for the largest level
+  Node *d_nodes = nullptr;
+  float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
+  int32_t *d_rank = nullptr;
+  Ctl *d_ctl = nullptr;
+  unsigned long long *d_totals = nullptr;  // [kStatCount + kMaxLevels + 1]
+  // timing
+  std::vector<TimedSpan> spans;
+  rtgpu_timings timings = {};
+};
+
+namespace {
+
+constexpr int kPartialBlocks = 1024;
+
+int fail(rtgpu_ctx *c, int code, const std::string &m) {
+  if (c) c->msg = m;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? RTGPU_E_MEMORY : RTGPU_E_NO_DEVICE,             \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+  } while (0)
+
+template <typename T>
+int dev_alloc(rtgpu_ctx *c, T **p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  HIPCHK(c, hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+  return RTGPU_OK;
+}
+template <typename T>
+void dev_free(T **p) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+struct Span {
+  rtgpu_ctx *c; int what; hipEvent_t a = nullptr, b = nullptr;
+  Span(rtgpu_ctx *ctx, int w) : c(ctx), what(w) {
+    if (c->opt_timing) {
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~Span() {
+    if (c->opt_timing) { (void)hipEventRecord(b, c->stream); c->spans.push_back({a, b, what}); }
+  }
+};
+
+void resolve_spans(rtgpu_ctx *c) {
+  float acc[W_COUNT] = {0};
+  int nn = 0, ns = 0;
+  for (auto &s : c->spans) {
+    float ms = 0.0f;
+    (void)hipEventSynchronize(s.b);
+    (void)hipEventElapsedTime(&ms, s.a, s.b);
+    acc[s.what] += ms;
+    if (s.what == W_NEAREST) nn++;
+    if (s.what == W_SHADOW) ns++;
+    (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+  }
+  if (!c->spans.empty()) {
+    c->timings = {acc[W_PRE], acc[W_GRID], acc[W_PRIMARY], acc[W_NEAREST], acc[W_HIT], acc[W_SHADOW], acc[W_ACCUM], acc[W_MINMAX], nn, ns};
+  }
+  c->spans.clear();
+}
+
+// glibc rand() with the default seed: random_r TYPE_3 (r[i] = r[i-3] + r[i-31], output >> 1) after
+// srandom_r(1)'s 310 warm-up draws.  The planar-light sampling of the reference consumes this stream.
+void glibc_rand_stream(std::vector<int32_t> &out, size_t n) {
+  uint32_t ring[31];
+  long word = 1;
+  ring[0] = 1;
+  for (int i = 1; i < 31; i++) {
+    long hi = word / 127773, lo = word % 127773;
+    word = 16807 * lo - 2836 * hi;
+    if (word < 0) word += 2147483647;
+    ring[i] = (uint32_t)word;
+  }
+  int f = 3, b = 0;
+  out.resize(n);
+  for (long long q = -310; q < (long long)n; q++) {
+    uint32_t v = ring[f] += ring[b];
+    if (q >= 0) out[q] = (int32_t)(v >> 1);
+    if (++f >= 31) f = 0;
+    if (++b >= 31) b = 0;
+  }
+}
+
+int64_t tiles_x_of(const rtgpu_ctx *c) { return (c->cam.sw + kTile - 1) / kTile; }
+int64_t tiles_y_of(const rtgpu_ctx *c) { return (c->cam.sh + kTile - 1) / kTile; }
+int64_t tiles_of_rank(int64_t ntiles, int rank, int world) { return rank < ntiles ? (ntiles - rank + world - 1) / world : 0; }
+
+// Queues of one chunk: level L holds at most cap[L] rays/nodes; a node has at most `fan` children.
+int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
+  if (tiles <= c->chunk_tiles_cap) return RTGPU_OK;
+  size_t total = 0, maxcap = 0;
+  for (int L = 0; L < c->levels; L++) {
+    c->cap[L] = L == 0 ? tiles * kTilePixels : c->cap[L - 1] * (size_t)c->fan;
+    c->base[L] = total;
+    total += c->cap[L];
+    maxcap = c->cap[L] > maxcap ? c->cap[L] : maxcap;
+  }
+  c->total_nodes = total;
+  int rc;
+  for (int L = 0; L < c->levels; L++)
+    if ((rc = dev_alloc(c, &c->d_rays[L], c->cap[L]))) return rc;
+  if ((rc = dev_alloc(c, &c->d_hits, maxcap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_nodes, total))) return rc;
+  if ((rc = dev_alloc(c, &c->d_colors, total * 4))) return rc;
+  if ((rc = dev_alloc(c, &c->d_ts, total * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)))) return rc;
+  if ((rc = dev_alloc(c, &c->d_rank, c->cap[0]))) return rc;
+  c->chunk_tiles_cap = tiles;
+  return RTGPU_OK;
+}
+
+size_t bytes_per_tile(const rtgpu_ctx *c) {
+  size_t nodes = 0, capL = kTilePixels, maxcap = 0;
+  for (int L = 0; L < c->levels; L++) {
+    if (L > 0) capL *= (size_t)c->fan;
+    nodes += capL;
+    maxcap = capL > maxcap ? capL : maxcap;
+  }
+  return nodes * (sizeof(Ray) + sizeof(Node) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) +
+         maxcap * sizeof(Hit) + kTilePixels * 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rtgpu_error_string(int code) {
+  switch (code) {
+    case RTGPU_OK: return "ok";
+    case RTGPU_E_IO: return "unable to read or write file";
+    case RTGPU_E_MEMORY: return "unable to allocate memory";
+    case RTGPU_E_NOT_ENOUGH_SURFACES: return "not enough surfaces to cover entire scene";
+    case RTGPU_E_INVALID_PARAM: return "parameter has invalid value";
+    case RTGPU_E_NO_DEVICE: return "no usable HIP device / HIP runtime error";
+    case RTGPU_E_STATE: return "call order violated";
+    case RTGPU_E_UNSUPPORTED: return "unsupported combination";
+    default: return "unknown error";
+  }
+}
+
+const char *rtgpu_last_message(const rtgpu_ctx *ctx) { return ctx ? ctx->msg.c_str() : ""; }
+
+int rtgpu_create(int device, rtgpu_ctx **out) {
+  if (!out) return RTGPU_E_INVALID_PARAM;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RTGPU_E_NO_DEVICE;
+  rtgpu_ctx *c = new rtgpu_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return RTGPU_E_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+  if (hipMalloc((void **)&c->d_ctl, sizeof(Ctl)) != hipSuccess ||
+      hipMalloc((void **)&c->d_totals, sizeof(unsigned long long) * 32) != hipSuccess ||
+      hipMalloc((void **)&c->d_partial, sizeof(float) * 6 * kPartialBlocks) != hipSuccess) {
+    rtgpu_destroy(c);
+    return RTGPU_E_MEMORY;
+  }
+  memset(&c->timings, 0, sizeof c->timings);
+  memset(&c->ginfo, 0, sizeof c->ginfo);
+  *out = c;
+  return RTGPU_OK;
+}
+
+void rtgpu_destroy(rtgpu_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  resolve_spans(c);
+  dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_sid); dev_free(&c->d_box);
+  dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
+  dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs);
+  for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
+  dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
+  dev_free(&c->d_rank); dev_free(&c->d_ctl); dev_free(&c->d_totals);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
+  if (!c || !name) return RTGPU_E_INVALID_PARAM;
+  if (!strcmp(name, "count")) c->opt_count = value != 0;
+  else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
+  else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
+  else if (!strcmp(name, "waves_per_cu")) { if (value < 1 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
+  else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
+  return RTGPU_OK;
+}
+
+int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
+  if (!c || !s || s->nt <= 0 || s->ns <= 0 || !s->vertices || !s->sid || !s->surfaces || s->nl < 0 || s->npl < 0 ||
+      (s->nl > 0 && !s->lights) || (s->npl > 0 && !s->planar))
+    return fail(c, RTGPU_E_INVALID_PARAM, "scene description incomplete");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int t = 0; t < s->nt; t++)
+    if (s->sid[t] < 0 || s->sid[t] >= s->ns) return fail(c, RTGPU_E_NOT_ENOUGH_SURFACES, "surface id out of range");
+  c->have_scene = c->have_frame = false;
+  c->nt = s->nt; c->ns = s->ns; c->nl = s->nl; c->npl = s->npl;
+  c->lights.assign(s->lights, s->lights + s->nl);
+  c->surfaces.assign(s->surfaces, s->surfaces + s->ns);
+  memcpy(c->dmin0, s->dmin, sizeof c->dmin0); memcpy(c->dmax0, s->dmax, sizeof c->dmax0);
+  c->gamma = s->gamma; c->distmod = s->distmod; c->vmode = s->vmode;
+  memcpy(c->vcoeff, s->vcoeff, sizeof c->vcoeff);
+  c->texture_present = s->texture_present;
+  // The texture goes to the 1st, 2nd, 7th and 8th triangle whose surface id is 7 (preprocess.c:41-79).
+  int seen = 0;
+  for (int q = 0; q < 4; q++) c->tex_tri[q] = -1;
+  for (int t = 0; t < s->nt; t++) {
+    if (s->sid[t] == 7) {
+      int slot = seen == 0 ? 0 : seen == 1 ? 1 : seen == 6 ? 2 : seen == 7 ? 3 : -1;
+      if (slot >= 0 && s->texture_present) c->tex_tri[slot] = t;
+      seen++;
+    }
+  }
+  // Secondary rays: a hit spawns a reflected ray if kr > 0 and a refracted one if kt > 0 (raytrace.c:193-204).
+  // Only surfaces some triangle uses can spawn anything.
+  std::vector<char> used(s->ns, 0);
+  for (int t = 0; t < s->nt; t++) used[s->sid[t]] = 1;
+  c->fan = 0;
+  for (int q = 0; q < s->ns; q++) {
+    if (!used[q]) continue;
+    int f = (s->surfaces[q].kr > 0.0f) + (s->surfaces[q].kt > 0.0f);
+    c->fan = f > c->fan ? f : c->fan;
+  }
+  c->levels = c->fan > 0 ? kMaxLevels : 1;
+  c->chunk_tiles_cap = 0;
+  if (c->npl > 0 && c->fan > 0)
+    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights together with reflective/transparent surfaces: the rand() replay "
+                                         "order of secondary hits is not implemented");
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_verts, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->d_geom, (size_t)s->nt * 9)) ||
+      (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
+      (rc = dev_alloc(c, &c->d_box, (size_t)s->nt * 6)) || (rc = dev_alloc(c, &c->d_surf, (size_t)s->ns)) ||
+      (rc = dev_alloc(c, &c->d_lights, (size_t)s->nl)) || (rc = dev_alloc(c, &c->d_planar, (size_t)s->npl)))
+    return rc;
+  static_assert(sizeof(rtgpu_surface) == sizeof(SurfaceD) && sizeof(rtgpu_light) == sizeof(LightD) &&
+                    sizeof(rtgpu_planar_light) == sizeof(PlanarD) && sizeof(rtgpu_camera) == sizeof(CameraD),
+                "ABI structs and device structs share one layout");
+  HIPCHK(c, hipMemcpyAsync(c->d_verts, s->vertices, sizeof(float) * 9 * s->nt, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_sid, s->sid, sizeof(int32_t) * s->nt, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_surf, s->surfaces, sizeof(SurfaceD) * s->ns, hipMemcpyHostToDevice, c->stream));
+  if (s->nl) HIPCHK(c, hipMemcpyAsync(c->d_lights, s->lights, sizeof(LightD) * s->nl, hipMemcpyHostToDevice, c->stream));
+  if (s->npl) HIPCHK(c, hipMemcpyAsync(c->d_planar, s->planar, sizeof(PlanarD) * s->npl, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_scene = true;
+  return RTGPU_OK;
+}
+
+int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
+  if (!c || !cam) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_scene) return fail(c, RTGPU_E_STATE, "no scene uploaded");
+  if (cam->sw <= 0 || cam->sh <= 0) return fail(c, RTGPU_E_INVALID_PARAM, "camera resolution must be positive");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_frame = false;
+  memcpy(&c->cam, cam, sizeof(CameraD));
+  // raytrace.c:346-355: total flux, and grow the domain so that it contains every point light
+  float dmin[3], dmax[3], total_flux = 0.0f;
+  memcpy(dmin, c->dmin0, sizeof dmin); memcpy(dmax, c->dmax0, sizeof dmax);
+  for (int k = 0; k < c->nl; k++) {
+    total_flux += c->lights[k].flux;
+    for (int i = 0; i < 3; i++) {
+      if (c->lights[k].p[i] < dmin[i]) dmin[i] = c->lights[k].p[i] - 0.001f;
+      if (c->lights[k].p[i] > dmax[i]) dmax[i] = c->lights[k].p[i] + 0.001f;
+    }
+  }
+  // rtUddCreate (voxelize.c:138-199), same expressions, same mixed float/double evaluation
+  float ds[3], cs[3];
+  int nv[3];
+  for (int k = 0; k < 3; k++) {
+    dmin[k] -= 0.001f;
+    dmax[k] += 0.001f;
+    ds[k] = (float)((double)(dmax[k] - dmin[k]) + 0.001);
+  }
+  if (c->vmode != 0)
+    for (int k = 0; k < 3; k++)
+      if (c->vcoeff[k] <= 0.0f) return fail(c, RTGPU_E_INVALID_PARAM, "voxelization coefficients must be > 0 in this voxmode");
+  float v = (float)pow((double)((float)c->nt / (ds[0] * ds[1] * ds[2])), (double)0.33333f);
+  for (int k = 0; k < 3; k++) {
+    float tmp;
+    if (c->vmode == 0) tmp = (float)ceil((double)(ds[k] * v));
+    else if (c->vmode == 1) tmp = (float)ceil((double)(ds[k] * v * c->vcoeff[k]));
+    else tmp = (float)ceil((double)c->vcoeff[k]);
+    nv[k] = (int)tmp;
+    cs[k] = ds[k] / tmp;
+  }
+  if (!(nv[0] > 0 && nv[1] > 0 && nv[2] > 0) || (double)nv[0] * nv[1] * nv[2] > 5e8)
+    return fail(c, RTGPU_E_INVALID_PARAM, "degenerate voxel grid");
+  const int ncells = nv[0] * nv[1] * nv[2];
+  int rc;
+  if ((size_t)ncells + 1 > c->cap_cells) {
+    if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1))) return rc;
+    c->cap_cells = (size_t)ncells + 1;
+  }
+  GridP g;
+  for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
+  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr;
+  const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
+  {
+    Span sp(c, W_PRE);
+    hipLaunchKernelGGL(k_preprocess, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, f3{cam->ob[0], cam->ob[1], cam->ob[2]}, c->d_geom, c->d_aux);
+  }
+  uint32_t nrefs = 0;
+  {
+    Span sp(c, W_GRID);
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), c->stream));
+    hipLaunchKernelGGL(k_tri_boxes, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, g, c->d_box, c->d_counts);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_counts, c->d_cell_start);
+    HIPCHK(c, hipMemcpyAsync(&nrefs, c->d_cell_start + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((size_t)nrefs > c->cap_refs) {
+      if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs))) return rc;
+      c->cap_refs = nrefs;
+    }
+    g.cell_tris = c->d_recs;
+    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_geom, c->d_sid,
+                       c->d_surf, c->d_recs, c->d_refs);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->grid = g;
+  for (int k = 0; k < 3; k++) { c->ginfo.nv[k] = nv[k]; c->ginfo.cell[k] = cs[k]; c->ginfo.dmin[k] = dmin[k]; c->ginfo.dmax[k] = dmax[k]; }
+  c->ginfo.ncells = ncells; c->ginfo.nrefs = (int32_t)nrefs; c->ginfo.total_flux = total_flux;
+  // planar lights: the reference draws 2 rand() values per sample, 16 samples per light, per shaded hit
+  if (c->npl > 0) {
+    size_t need = (size_t)cam->sw * cam->sh * c->npl * kPlanarSamples * 2;
+    if (need > c->cap_rand) {
+      std::vector<int32_t> tab;
+      glibc_rand_stream(tab, need);
+      if ((rc = dev_alloc(c, &c->d_rand, need))) return rc;
+      HIPCHK(c, hipMemcpy(c->d_rand, tab.data(), need * sizeof(int32_t), hipMemcpyHostToDevice));
+      c->cap_rand = need;
+    }
+  }
+  ShadeP sp;
+  sp.surf = c->d_surf; sp.lights = c->d_lights; sp.planar = c->d_planar; sp.tri_aux = c->d_aux; sp.tri_sid = c->d_sid;
+  sp.rand_tab = c->npl > 0 ? c->d_rand : nullptr;
+  sp.nl = c->nl; sp.npl = c->npl; sp.nslots = c->nl + kPlanarSamples * c->npl;
+  for (int q = 0; q < 4; q++) sp.tex_tri[q] = c->tex_tri[q];
+  sp.total_flux = total_flux; sp.distmod = c->distmod;
+  if (sp.nslots != c->shade.nslots) c->chunk_tiles_cap = 0;
+  c->shade = sp;
+  c->have_frame = true;
+  return RTGPU_OK;
+}
+
+int rtgpu_grid_info_get(const rtgpu_ctx *c, rtgpu_grid_info *out) {
+  if (!c || !out) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return RTGPU_E_STATE;
+  *out = c->ginfo;
+  return RTGPU_OK;
+}
+
+int64_t rtgpu_tile_count(const rtgpu_ctx *c, int rank, int world) {
+  if (!c || !c->have_frame || world <= 0 || rank < 0 || rank >= world) return -1;
+  return tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
+}
+
+int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax) {
+  if (!c || !d_rgb || !d_ids || !d_minmax || world <= 0 || rank < 0 || rank >= world) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
+  if (c->npl > 0 && world != 1)
+    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights need the whole image on one GPU (rand() replay order)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t tx = tiles_x_of(c), ntiles = tiles_of_rank(tx * tiles_y_of(c), rank, world);
+  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, d_minmax);
+  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 32, c->stream));
+  if (ntiles == 0) return RTGPU_OK;
+  size_t per_tile = bytes_per_tile(c);
+  int64_t chunk = (int64_t)(c->chunk_bytes / (int64_t)per_tile);
+  if (chunk < 1) chunk = 1;
+  if (chunk > ntiles) chunk = ntiles;
+  if (c->npl > 0 && chunk < ntiles)
+    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights need the whole image in one chunk; raise chunk_bytes");
+  if ((int64_t)chunk * kTilePixels * (c->fan > 1 ? 16 : 1) > 0x7fffffffll) chunk = 0x7fffffffll / (kTilePixels * (c->fan > 1 ? 16 : 1));
+  int rc = ensure_chunk(c, (size_t)chunk);
+  if (rc) return rc;
+  const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
+  for (int64_t t0 = 0; t0 < ntiles; t0 += chunk) {
+    const int nt_chunk = (int)((ntiles - t0) < chunk ? (ntiles - t0) : chunk);
+    const int n0 = nt_chunk * kTilePixels;
+    HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream));
+    {
+      Span sp(c, W_PRIMARY);
+      hipLaunchKernelGGL(k_primary, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, c->cam, c->grid, (int)t0, nt_chunk, rank, world,
+                         (int)tx, c->d_rays[0], c->d_ctl);
+    }
+    for (int L = 0; L < c->levels; L++) {
+      const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+      {
+        Span sp(c, W_NEAREST);
+        if (c->opt_count)
+          hipLaunchKernelGGL(k_nearest<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
+        else
+          hipLaunchKernelGGL(k_nearest<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
+      }
+      {
+        Span sp(c, W_HIT);
+        const bool spawn = L + 1 < c->levels;
+        hipLaunchKernelGGL(k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
+                           c->d_nodes, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
+                           spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn);
+      }
+    }
+    if (c->npl > 0)
+      hipLaunchKernelGGL(k_hit_rank, dim3(1), dim3(1024), 0, c->stream, c->cam.sw, c->cam.sh, (int)tx, c->d_nodes, c->d_rank);
+    if (c->shade.nslots > 0) {
+      for (int L = 0; L < c->levels; L++) {
+        Span sp(c, W_SHADOW);
+        const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
+        if (c->opt_count)
+          hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+        else
+          hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+      }
+    }
+    for (int L = c->levels - 1; L >= 0; L--) {
+      Span sp(c, W_ACCUM);
+      const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+      hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->shade, c->d_rays[L], c->d_nodes,
+                         c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels);
+    }
+    {
+      Span sp(c, W_MINMAX);
+      int blocks = (n0 + 255) / 256;
+      if (blocks > kPartialBlocks) blocks = kPartialBlocks;
+      hipLaunchKernelGGL(k_minmax_partial, dim3(blocks), dim3(256), 0, c->stream, c->d_nodes, c->d_colors, n0, c->d_partial);
+      hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, c->stream, c->d_partial, blocks, d_minmax);
+    }
+    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, c->stream, c->d_ctl, c->d_totals);
+  }
+  HIPCHK(c, hipGetLastError());
+  return RTGPU_OK;
+}
+
+int rtgpu_tonemap(rtgpu_ctx *c, const float *d_rgb, int64_t n, const float *d_minmax, float gamma, uint32_t *d_rgba) {
+  if (!c || !d_rgb || !d_minmax || !d_rgba || n < 0) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n == 0) return RTGPU_OK;
+  hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_rgb, (long long)n, d_minmax, gamma, d_rgba);
+  HIPCHK(c, hipGetLastError());
+  return RTGPU_OK;
+}
+
+int rtgpu_untile(rtgpu_ctx *c, const void *d_gathered, int world, int elem_bytes, void *d_image) {
+  if (!c || !d_gathered || !d_image || world <= 0 || elem_bytes <= 0 || elem_bytes % 4) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return RTGPU_E_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  const long long n = (long long)c->cam.sw * c->cam.sh, tx = tiles_x_of(c), ntiles = tx * tiles_y_of(c);
+  hipLaunchKernelGGL(k_untile, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)d_gathered, world, c->cam.sw,
+                     c->cam.sh, (int)tx, ntiles, elem_bytes / 4, (uint32_t *)d_image);
+  HIPCHK(c, hipGetLastError());
+  return RTGPU_OK;
+}
+
+int rtgpu_sync(rtgpu_ctx *c) {
+  if (!c) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RTGPU_OK;
+}
+
+int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
+  if (!c || !out) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long h[32];
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(h, c->d_totals, sizeof h, hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof *out);
+  out->pixels = (int64_t)h[kPixels];
+  out->pixels_traced = (int64_t)h[kPixelsTraced];
+  int64_t secondary = 0;
+  for (int L = 1; L < kMaxLevels; L++) secondary += (int64_t)h[kStatCount + L];
+  out->nearest_queries = out->pixels_traced + secondary;
+  out->shadow_queries = (int64_t)h[kShaded] * c->shade.nslots;
+  out->shadow_walks = (int64_t)h[kShadowWalks];
+  out->nearest_steps = (int64_t)h[kNearS]; out->nearest_tests = (int64_t)h[kNearT];
+  out->shadow_steps = (int64_t)h[kShadS]; out->shadow_tests = (int64_t)h[kShadT];
+  return RTGPU_OK;
+}
+
+int rtgpu_timings_get(rtgpu_ctx *c, rtgpu_timings *out) {
+  if (!c || !out) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  resolve_spans(c);
+  *out = c->timings;
+  return RTGPU_OK;
+}
+
+int rtgpu_render_host(rtgpu_ctx *c, float *rgb, int32_t *ids, float *minmax) {
+  if (!c) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t nt = rtgpu_tile_count(c, 0, 1), npx = (int64_t)c->cam.sw * c->cam.sh;
+  float *d_rgb_t = nullptr, *d_rgb = nullptr, *d_mm = nullptr;
+  int32_t *d_ids_t = nullptr, *d_ids = nullptr;
+  int rc = RTGPU_OK;
+  if ((rc = dev_alloc(c, &d_rgb_t, (size_t)nt * kTilePixels * 3)) || (rc = dev_alloc(c, &d_ids_t, (size_t)nt * kTilePixels)) ||
+      (rc = dev_alloc(c, &d_rgb, (size_t)npx * 3)) || (rc = dev_alloc(c, &d_ids, (size_t)npx)) || (rc = dev_alloc(c, &d_mm, 6))) {
+  } else if ((rc = rtgpu_render(c, 0, 1, d_rgb_t, d_ids_t, d_mm)) || (rc = rtgpu_untile(c, d_rgb_t, 1, 12, d_rgb)) ||
+             (rc = rtgpu_untile(c, d_ids_t, 1, 4, d_ids))) {
+  } else {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && rgb) e = hipMemcpy(rgb, d_rgb, sizeof(float) * 3 * npx, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ids) e = hipMemcpy(ids, d_ids, sizeof(int32_t) * npx, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && minmax) e = hipMemcpy(minmax, d_mm, sizeof(float) * 6, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(c, RTGPU_E_NO_DEVICE, std::string("render_host: ") + hipGetErrorString(e));
+  }
+  dev_free(&d_rgb_t); dev_free(&d_ids_t); dev_free(&d_rgb); dev_free(&d_ids); dev_free(&d_mm);
+  return rc;
+}
+
+int rtgpu_tonemap_host(rtgpu_ctx *c, const float *rgb, int64_t n, const float *minmax, float gamma, uint32_t *rgba) {
+  if (!c || !rgb || !minmax || !rgba || n < 0) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  float *d_rgb = nullptr, *d_mm = nullptr;
+  uint32_t *d_out = nullptr;
+  int rc = RTGPU_OK;
+  if ((rc = dev_alloc(c, &d_rgb, (size_t)n * 3)) || (rc = dev_alloc(c, &d_mm, 6)) || (rc = dev_alloc(c, &d_out, (size_t)n))) {
+  } else {
+    hipError_t e = hipMemcpy(d_rgb, rgb, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_mm, minmax, sizeof(float) * 6, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = rtgpu_tonemap(c, d_rgb, n, d_mm, gamma, d_out);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && !rc) e = hipMemcpy(rgba, d_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(c, RTGPU_E_NO_DEVICE, std::string("tonemap_host: ") + hipGetErrorString(e));
+  }
+  dev_free(&d_rgb); dev_free(&d_mm); dev_free(&d_out);
+  return rc;
+}
+
+int rtgpu_grid_download(rtgpu_ctx *c, int32_t *cell_start, int32_t *refs) {
+  if (!c) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return RTGPU_E_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (cell_start) HIPCHK(c, hipMemcpy(cell_start, c->d_cell_start, sizeof(uint32_t) * ((size_t)c->ginfo.ncells + 1), hipMemcpyDeviceToHost));
+  if (refs && c->ginfo.nrefs > 0) HIPCHK(c, hipMemcpy(refs, c->d_refs, sizeof(int32_t) * (size_t)c->ginfo.nrefs, hipMemcpyDeviceToHost));
+  return RTGPU_OK;
+}
+
+int rtgpu_triangles_download(rtgpu_ctx *c, float *out10) {
+  if (!c || !out10) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return RTGPU_E_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<float> geom((size_t)c->nt * 9), aux((size_t)c->nt * 4);
+  HIPCHK(c, hipMemcpy(geom.data(), c->d_geom, geom.size() * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(aux.data(), c->d_aux, aux.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (int t = 0; t < c->nt; t++) {
+    float *o = out10 + 10 * (size_t)t;
+    for (int k = 0; k < 3; k++) { o[k] = aux[4 * (size_t)t + k]; o[3 + k] = geom[9 * (size_t)t + 3 + k]; o[6 + k] = geom[9 * (size_t)t + 6 + k]; }
+    o[9] = aux[4 * (size_t)t + 3];
+  }
+  return RTGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+/* Command line of the ray tracer: the reference's options (src/main.c:36-104) plus -W/-H to override
+ * the camera resolution, -d to pick the GPU and -I to dump primary-hit triangle ids.
+ */
+#include "rt_host.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static void usage(const char *exe) {
+  printf("usage: %s [options]\n\n"
+         "    -g PATH  geometry (.brs)      -l PATH  point lights (.lgt)   -L PATH  planar lights (.pnr)\n"
+         "    -a PATH  attributes (.atr)    -c PATH  camera (.cam)         -C PATH  renderer config (.cfg)\n"
+         "    -s PREFIX  PREFIX.brs/.lgt/.atr/.cam/.cfg/.pnr for everything not given explicitly\n"
+         "    -o PATH  output image (24-bpp BMP)\n"
+         "    -G gamma   -E epsilon   -D distmod   (a .cfg file overrides them)\n"
+         "    -W width -H height  override the camera resolution    -d N  GPU index\n"
+         "    -I PATH  also write primary-hit triangle ids (int32, row-major, -1 = none)\n", exe);
+}
+
+static char *join(const char *a, const char *b) {
+  char *r = malloc(strlen(a) + strlen(b) + 1);
+  strcpy(r, a); strcat(r, b);
+  return r;
+}
+
+int main(int argc, char **argv) {
+  const char *opt[128] = {0};
+  const char *letters = "glLacCsoGEDWHdI";
+  char *g, *l, *L, *a, *c, *C;
+  float gamma = 2.5f, epsilon = 0.0f, distmod = 2.0f;
+  int i;
+  if (argc <= 1) { usage(argv[0]); return 0; }
+  for (i = 1; i < argc; i++) { /* value glued to the option ("-sPREFIX") or in the next argument */
+    const char *arg = argv[i];
+    if (arg[0] != '-' || !arg[1] || !strchr(letters, arg[1])) { fprintf(stderr, "unknown option %s\n", arg); return 1; }
+    if (arg[2]) opt[(int)arg[1]] = arg + 2;
+    else if (i + 1 < argc) opt[(int)arg[1]] = argv[++i];
+  }
+  if (opt['G']) sscanf(opt['G'], "%f", &gamma);
+  if (opt['E']) sscanf(opt['E'], "%f", &epsilon);
+  if (opt['D']) sscanf(opt['D'], "%f", &distmod);
+  if ((!opt['s'] && (!opt['g'] || (!opt['l'] && !opt['L']) || !opt['a'] || !opt['c'])) || !opt['o']) {
+    fprintf(stderr, "some of required options are missing\n");
+    return 0;
+  }
+  g = opt['g'] ? strdup(opt['g']) : join(opt['s'], ".brs");
+  l = opt['l'] ? strdup(opt['l']) : opt['s'] ? join(opt['s'], ".lgt") : NULL;
+  a = opt['a'] ? strdup(opt['a']) : join(opt['s'], ".atr");
+  c = opt['c'] ? strdup(opt['c']) : join(opt['s'], ".cam");
+  C = opt['C'] ? strdup(opt['C']) : opt['s'] ? join(opt['s'], ".cfg") : NULL;
+  L = opt['L'] ? strdup(opt['L']) : opt['s'] ? join(opt['s'], ".pnr") : NULL;
+  if (opt['d']) rtHostSetDevice(atoi(opt['d']));
+
+  errno = 0;
+  RT_Scene *scene = rtSceneLoadAll(g, l, L, a, C, gamma, epsilon, distmod);
+  if (!scene) { fprintf(stderr, "unable to load scene: %s\n", rtGetErrorDesc()); return 1; }
+  RT_Camera *cam = rtCameraLoad(c);
+  if (!cam || errno > 0) { fprintf(stderr, "unable to load camera: %s\n", rtGetErrorDesc()); return 1; }
+  if (opt['W'] && opt['H']) { cam->sw = atoi(opt['W']); cam->sh = atoi(opt['H']); }
+
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  RT_VisualizedScene *vs = rtVisualizedSceneRaytrace(scene, cam);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (errno > 0) { fprintf(stderr, "errno set by ray-trace process: %d, %s\n", errno, rtGetErrorDesc()); errno = 0; }
+  if (!vs) return 1;
+  printf("...ray-tracing done. Time taken: %.3f seconds\n", (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
+  if (opt['I']) {
+    FILE *f = fopen(opt['I'], "wb");
+    size_t p, np = (size_t)vs->width * vs->height;
+    for (p = 0; f && p < np; p++) {
+      int32_t id = vs->map[p].t ? (int32_t)(vs->map[p].t - scene->t) : -1;
+      fwrite(&id, 4, 1, f);
+    }
+    if (f) fclose(f);
+  }
+  RT_Bitmap *bmp = rtVisualizedSceneToBitmap(vs, F_HDR, NULL);
+  if (bmp) rtBitmapSave(bmp, opt['o'], 24);
+  rtBitmapDestroy(&bmp);
+  rtVisualizedSceneDestroy(&vs);
+  rtCameraDestroy(&cam);
+  rtSceneDestroy(&scene);
+  rtHostShutdown();
+  if (errno > 0) { fprintf(stderr, "problem while creating result image: %d, %s\n", errno, rtGetErrorDesc()); return 1; }
+  return 0;
+}
