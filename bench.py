@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-pixel trace path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene temple] [--width 3840 --height 2160]
+
+Workload (N=1 and N>1 alike): scenes/temple at 3840x2160, the configuration the headline metric is
+quoted on.  One step = one frame = everything the reference's rtVisualizedSceneRaytrace +
+rtVisualizedSceneToBitmap do: per-triangle preprocess, grid build, primary rays, nearest-hit walks,
+shading with one shadow query per (hit, light), global min/max, tone map to RGBA8, and with N>1 the
+min/max all-reduce and the RGBA8 tile gather to rank 0 (RCCL).  The scene is uploaded to HBM before
+the timed region; the finished image stays in HBM on rank 0.  The frame is split by 8x8 tiles over
+the ranks, so total work is fixed as N grows ("strong" scaling).
+
+metric = Mrays/s, rays counted as the reference issues them (nearest-hit queries + shadow queries,
+back-face early-outs included): 40,689,192 per temple 4K frame.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (shadow or nearest walk): algorithmic bytes per launch
+                (64 B per ray + 8 B per visited voxel + 40 B per listed triangle, S and T counted by the
+                kernel's own counting variant in an untimed pass) / its average launch duration from HIP
+                events on the launch stream.  The scene is cache-resident, so this logical rate can
+                exceed the HBM peak; valu_lane_ops_frac prices the same launch against fp32 VALU issue.
+  cpu_baseline  the unmodified reference (oracle/_ref/ref_dump) or, if that binary is absent, the C
+                oracle, single-threaded on the host, on the same scene at a reduced resolution.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # HBM3E peak, GB/s
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x Hz: fp32 vector instructions (lane-ops) per second
+
+
+def cpu_baseline(prefix, over, width, height):
+    """Times the CPU path on one host core on a bounded sample: the same scene at width x height."""
+    import raytracer_amd as rt
+    from oracle import oracle as O
+    # rays of the sample, counted by the reference's own definition (the GPU path issues the same queries)
+    scene = rt.Scene(prefix, width=width, height=height, **over)
+    r = rt.Renderer(0)
+    r.upload(scene)
+    r.frame_begin()
+    r.render_host()
+    rays = r.counters().rays
+    r.close()
+    sample = "%s at %dx%d, whole frame, 1 thread" % (os.path.basename(prefix), width, height)
+    if O.have_reference():
+        ref = O.run_reference(prefix, width=width, height=height, cwd=os.path.join(ROOT, "scenes"), **over)
+        secs, kind = ref["seconds"], "reference"
+    else:
+        s = O.OracleScene(prefix, width=width, height=height, **over)
+        t0 = time.time()
+        s.render(shadow_cache=True, threads=1)
+        secs, kind = time.time() - t0, "port"
+    return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": kind, "sample": sample,
+            "seconds": round(secs, 3), "rays": rays}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="temple")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-width", type=int, default=640)
+    ap.add_argument("--cpu-height", type=int, default=360)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd.dist import FrameRenderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scenes = {"temple": ("scenes/temple/temple", {}), "ulica": ("scenes/ulica/ulica", {}), "s3": ("scenes/s3/s3", {}),
+              "s5": ("scenes/s5/s5", {}), "pokoj": ("scenes/pokoj/s2", {}), "s2": ("scenes/s2/s2", {})}
+    prefix, over = scenes[args.scene]
+    prefix = os.path.join(ROOT, prefix)
+    scene = rt.Scene(prefix, width=args.width, height=args.height, **over)
+    renderer = rt.Renderer(local_rank)
+
+    # untimed counting pass: rays per frame, S and T per kernel family for the roofline (this rank's tiles)
+    renderer.set_option("count", 1)
+    fr = FrameRenderer(renderer, scene, rank, world)
+    fr.frame()
+    torch.cuda.synchronize(dev)
+    cnt = renderer.counters().asdict()
+    renderer.set_option("count", 0)
+    renderer.set_option("timing", 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        fr.frame()
+    barrier()
+    renderer.timings()  # drop what warm-up accumulated
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fr.frame()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tim = renderer.timings().asdict()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays_t = torch.tensor([cnt["nearest_queries"] + cnt["shadow_queries"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    rays_frame = float(rays_t.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        # dominant kernel on this rank
+        fam = "shadow" if tim["shadow_ms"] >= tim["nearest_ms"] else "nearest"
+        launches = max(tim[fam + "_launches"], 1)
+        avg_ms = tim[fam + "_ms"] / launches
+        if fam == "shadow":
+            q, S, T = cnt["shadow_queries"], cnt["shadow_steps"], cnt["shadow_tests"]
+        else:
+            q, S, T = cnt["nearest_queries"], cnt["nearest_steps"], cnt["nearest_tests"]
+        per_launch = args.steps / launches  # frames per launch of this family (1 when the frame is one chunk)
+        alg_bytes = (64.0 * q + 8.0 * S + 40.0 * T) * per_launch
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # the same launch priced against vector issue: ~30 fp32 lane-ops per listed triangle (Moeller-Trumbore, no FMA)
+        valu_frac = (30.0 * T * per_launch) / (avg_ms * 1e-3) / VALU_LANE_OPS if avg_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("k_" + fam, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+secondary)", "value": round(rays_frame * args.steps / elapsed / 1e6, 3),
+            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "bundled scene scenes/%s (the reference's own input), camera resolution set to %dx%d"
+                                    % (args.scene, args.width, args.height),
+            "config": {"workload": "scenes/%s %dx%d, depth 5, %d point lights, frame = preprocess + grid build + trace + "
+                                   "shade + tone map%s" % (args.scene, args.width, args.height, scene.nl,
+                                                            " + RCCL min/max all-reduce + RGBA8 tile gather" if world > 1 else ""),
+                       "rays_per_frame": int(rays_frame), "tiling": "8x8 tiles round-robin over %d rank(s)" % world},
+            "kernel_ms_per_frame_rank0": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
+            "roofline": {"bound": "hbm", "kernel": "k_" + fam, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "valu_lane_ops_frac": round(valu_frac, 4),
+                         "note": "logical bytes (64 B/ray + 8 B/voxel + 40 B/listed triangle); the scene is cache-resident, "
+                                 "so frac can exceed 1 without touching HBM; the kernel is fp32-VALU bound"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(prefix, over, args.cpu_width, args.cpu_height)
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,8 +3,8 @@
  * This is the drop-in boundary.  The reference renders a frame with one call,
  *     RT_VisualizedScene* rtVisualizedSceneRaytrace(RT_Scene*, RT_Camera*)   (src/raytrace.h:57)
  * followed by rtVisualizedSceneToBitmap (src/raytrace.h:64).  A host that keeps the reference's
- * loaders and BMP writer replaces the body of those two functions with the calls below (the stub is
- * shown in INTEGRATION.md; raytracer_amd/host/raytrace.c is a complete host built that way).
+ * loaders and BMP writer replaces the body of those two functions with the calls below
+ * (raytracer_amd/host/raytrace.c is a complete host built that way).
  *
  * Only plain-old-data crosses this boundary: counts, float/int arrays, opaque handle.  Every function
  * returns 0 on success or an RTGPU_E_* code; the codes 1..7 are the reference's errno values
@@ -85,8 +85,8 @@ typedef struct rtgpu_grid_info {
   float total_flux;    /* src/raytrace.c:346-348 */
 } rtgpu_grid_info;
 
-/* Ray statistics of the last rtgpu_render call, counted the way SURVEY/BASELINE define "rays":
- * nearest-hit queries + shadow queries as the reference issues them. */
+/* Ray statistics of the last rtgpu_render call.  "Rays" are counted as the reference issues them:
+ * nearest-hit queries + shadow queries. */
 typedef struct rtgpu_counters {
   int64_t pixels;          /* pixels of this rank's tiles inside the image */
   int64_t pixels_traced;   /* ... whose primary ray entered the grid */
@@ -97,8 +97,8 @@ typedef struct rtgpu_counters {
   int64_t shadow_steps, shadow_tests;   /* S and T of the shadow walks   (only with option "count" = 1) */
 } rtgpu_counters;
 
-/* Per-kernel device time of the last rtgpu_frame_begin + rtgpu_render, from HIP events on the
- * context's stream (only with option "timing" = 1; the events serialise the kernels). */
+/* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP
+ * events recorded around every launch on the context's stream (only with option "timing" = 1). */
 typedef struct rtgpu_timings {
   float preprocess_ms, grid_ms, primary_ms, nearest_ms, hit_ms, shadow_ms, accumulate_ms, minmax_ms;
   int32_t nearest_launches, shadow_launches;
@@ -112,6 +112,11 @@ const char *rtgpu_last_message(const rtgpu_ctx *ctx);
  * is no usable GPU: there is no CPU fallback. */
 int rtgpu_create(int device, rtgpu_ctx **out);
 void rtgpu_destroy(rtgpu_ctx *ctx);
+
+/* Makes the context enqueue on the caller's HIP stream (a hipStream_t, e.g. torch's current stream)
+ * instead of its own, so that rendering orders with the caller's collectives without host syncs.
+ * NULL switches back to the context's own stream. */
+int rtgpu_set_stream(rtgpu_ctx *ctx, void *hip_stream);
 
 /* Options: "count" (0/1) S/T counters, "timing" (0/1) per-kernel events, "chunk_bytes" (device
  * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size). */

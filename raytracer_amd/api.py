@@ -108,6 +108,7 @@ def gpu_lib():
         L.rtgpu_destroy.argtypes = [vp]
         L.rtgpu_destroy.restype = None
         L.rtgpu_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.rtgpu_set_stream.argtypes = [vp, vp]
         L.rtgpu_scene_upload.argtypes = [vp, C.POINTER(SceneDesc)]
         L.rtgpu_frame_begin.argtypes = [vp, C.POINTER(Camera)]
         L.rtgpu_grid_info_get.argtypes = [vp, C.POINTER(GridInfo)]
@@ -285,6 +286,11 @@ class Renderer:
 
     def set_option(self, name, value):
         self._chk(self._L.rtgpu_set_option(self._h, name.encode(), int(value)), "rtgpu_set_option(%s)" % name)
+
+    def set_stream(self, stream):
+        """stream: a torch.cuda.Stream, a raw hipStream_t handle, or None for the context's own stream."""
+        h = getattr(stream, "cuda_stream", stream)
+        self._chk(self._L.rtgpu_set_stream(self._h, C.c_void_p(h) if h else None), "rtgpu_set_stream")
 
     def upload(self, scene):
         self._chk(self._L.rtgpu_scene_upload(self._h, C.byref(scene.desc)), "rtgpu_scene_upload")

@@ -26,7 +26,7 @@ enum What { W_PRE = 0, W_GRID, W_PRIMARY, W_NEAREST, W_HIT, W_SHADOW, W_ACCUM, W
 
 struct rtgpu_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, own_stream = nullptr;
   int num_cu = 256;
   std::string msg;
   // options
@@ -217,10 +217,11 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RTGPU_E_NO_DEVICE;
   rtgpu_ctx *c = new rtgpu_ctx();
   c->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return RTGPU_E_NO_DEVICE;
   }
+  c->stream = c->own_stream;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
   if (hipMalloc((void **)&c->d_ctl, sizeof(Ctl)) != hipSuccess ||
@@ -246,8 +247,16 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->d_rank); dev_free(&c->d_ctl); dev_free(&c->d_totals);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+}
+
+int rtgpu_set_stream(rtgpu_ctx *c, void *hip_stream) {
+  if (!c) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return RTGPU_OK;
 }
 
 int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {

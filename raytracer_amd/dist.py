@@ -1,0 +1,123 @@
+"""Image-tile data parallelism over the GPUs of one node (one process per GPU, torch.distributed).
+
+The frame is cut into 8x8-pixel tiles dealt round-robin to the ranks (cost per pixel varies by two
+orders of magnitude across an image, so fine interleaving is the load balancer).  Every rank holds the
+whole scene and traces only its tiles; there is exactly one exchange per frame:
+
+  1. all-reduce MIN and MAX of the per-channel colour range (3 floats each): the tone map divides by
+     the GLOBAL range (src/raytrace.c:396-399, 433-435 of the reference), so it cannot start earlier;
+  2. every rank tone-maps its own tiles to RGBA8;
+  3. the RGBA8 tiles (4 B/pixel) are gathered to rank 0, which de-interleaves them into the image.
+
+On ROCm the "nccl" backend is RCCL; the gather is a set of direct peer->root transfers over xGMI.
+The same functions run on CPU tensors with the gloo backend (used by the CPU tests).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TILE = 8
+TILE_PIXELS = 64
+
+
+def tiles_of(width, height):
+    return ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
+
+
+def tile_count(ntiles, rank, world):
+    """Number of tiles rank owns when tiles rank, rank+world, ... belong to it."""
+    return (ntiles - rank + world - 1) // world if rank < ntiles else 0
+
+
+def exchange_minmax(minmax, group=None):
+    """minmax: tensor [6] = min rgb, max rgb of this rank.  Returns the global range on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return minmax
+    lo, hi = minmax[:3].clone(), minmax[3:].clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return torch.cat([lo, hi])
+
+
+def gather_tiles(local, ntiles, elems_per_pixel=1, dst=0, group=None):
+    """Gathers tile-major buffers (tile_count(rank)*64*elems elements each) to `dst`.
+
+    Returns on dst a tensor laid out rank-major (rank 0's tiles, then rank 1's, ...) with exactly
+    tile_count(r)*64*elems elements per rank, which is the layout rtgpu_untile reads; None elsewhere.
+    Ranks own different tile counts when ntiles % world != 0, so buffers are padded to the largest.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return local
+    per_tile = TILE_PIXELS * elems_per_pixel
+    most = tile_count(ntiles, 0, world) * per_tile
+    send = local
+    if local.numel() < most:
+        send = torch.zeros(most, dtype=local.dtype, device=local.device)
+        send[:local.numel()] = local
+    parts = [torch.empty(most, dtype=local.dtype, device=local.device) for _ in range(world)] if rank == dst else None
+    dist.gather(send, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][:tile_count(ntiles, r, world) * per_tile] for r in range(world)])
+
+
+def split_tiles_reference(image, rank, world):
+    """numpy: the tile-major buffer rank would produce for a row-major [h, w, ...] image."""
+    h, w = image.shape[:2]
+    tx, ty = (w + TILE - 1) // TILE, (h + TILE - 1) // TILE
+    pad = np.zeros((ty * TILE, tx * TILE) + image.shape[2:], image.dtype)
+    pad[:h, :w] = image
+    tiles = pad.reshape((ty, TILE, tx, TILE) + image.shape[2:]).swapaxes(1, 2).reshape((ty * tx, TILE_PIXELS) + image.shape[2:])
+    return tiles[rank::world].copy()
+
+
+def untile_reference(gathered, world, width, height):
+    """numpy inverse of the rank-major tile layout: gathered [ntiles*64, ...] -> [h, w, ...]."""
+    tx, ty = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    ntiles = tx * ty
+    g = gathered.reshape((ntiles, TILE_PIXELS) + gathered.shape[1:])
+    tiles = np.zeros_like(g)
+    at = 0
+    for r in range(world):
+        n = tile_count(ntiles, r, world)
+        tiles[r::world] = g[at:at + n]
+        at += n
+    img = tiles.reshape((ty, tx, TILE, TILE) + gathered.shape[1:]).swapaxes(1, 2).reshape((ty * TILE, tx * TILE) + gathered.shape[1:])
+    return img[:height, :width].copy()
+
+
+class FrameRenderer:
+    """Per-rank driver of one frame: trace own tiles, exchange the range, tone-map, gather, untile."""
+
+    def __init__(self, renderer, scene, rank=0, world=1, group=None):
+        self.r, self.scene, self.rank, self.world, self.group = renderer, scene, rank, world, group
+        dev = torch.device("cuda", renderer.device)
+        self.dev = dev
+        renderer.upload(scene)
+        renderer.frame_begin()
+        self.w, self.h = scene.width, scene.height
+        self.ntiles = tiles_of(self.w, self.h)
+        n = renderer.tile_count(rank, world) * TILE_PIXELS
+        self.npix_local = n
+        self.rgb = torch.zeros(max(n, 1) * 3, dtype=torch.float32, device=dev)
+        self.ids = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        self.minmax = torch.zeros(6, dtype=torch.float32, device=dev)
+        self.rgba = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        self.image = torch.zeros(self.w * self.h, dtype=torch.int32, device=dev) if rank == 0 else None
+        renderer.set_stream(torch.cuda.current_stream(dev))
+
+    def frame(self):
+        """One frame: everything rtVisualizedSceneRaytrace + rtVisualizedSceneToBitmap do, on `world` GPUs.
+        Returns the row-major RGBA8 image (int32 tensor, w*h) on rank 0."""
+        r = self.r
+        r.frame_begin()                                    # preprocess + grid build (replicated)
+        r.render(self.rgb, self.ids, self.minmax, self.rank, self.world)
+        mm = exchange_minmax(self.minmax, self.group)      # exchange 1: 2 x 3 floats
+        r.tonemap(self.rgb, self.npix_local, mm, self.scene.gamma, self.rgba)
+        self.global_minmax = mm
+        gathered = gather_tiles(self.rgba[:self.npix_local], self.ntiles, 1, 0, self.group)  # exchange 2: 4 B/pixel
+        if self.rank == 0:
+            r.untile(gathered, self.world, 4, self.image)
+        return self.image

@@ -1,6 +1,6 @@
 """Parity of the HIP trace path (through the C ABI of librtgpu.so) with the reference.
 
-Bars (BASELINE.json north_star): primary-hit triangle ids bit-exact; 8-bit RGB within 1/255 per channel.
+Bars: primary-hit triangle ids bit-exact; 8-bit RGB within 1/255 per channel.
 Checked three ways:
   * against the committed golden dumps of the unmodified reference (tests/golden/*.npz),
   * against the CPU oracle on the same inputs (grid lists, per-triangle preprocess, raw float colour),

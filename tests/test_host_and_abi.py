@@ -1,0 +1,95 @@
+"""CPU-only checks: the C host layer against the oracle's loaders, the BMP writer, and that the C-ABI
+library loads and exports every symbol include/rtgpu.h declares (no compute without a GPU)."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = [("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}), ("scenes/s2/s2", {}), ("scenes/s3/s3", {}),
+          ("scenes/s5/s5", {}), ("scenes/pokoj/s2", {}), ("scenes/temple/temple", {}), ("scenes/ulica/ulica", {})]
+
+
+def test_abi_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "rtgpu.h")).read()
+    names = sorted(set(re.findall(r"\b(rtgpu_[a-z_]+)\s*\(", text)))
+    assert len(names) >= 18
+    lib = rt.gpu_lib()
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_host_layer_exports_reference_entry_points():
+    lib = rt.host_lib()
+    for n in ["rtSceneLoad", "rtSceneConfigureRenderer", "rtSceneSetSurfaces", "rtSceneSetLights", "rtSceneSetPlanarLights",
+              "rtSceneDestroy", "rtLightLoad", "rtPlanarLightLoad", "rtSurfaceLoad", "rtCameraLoad", "rtCameraDestroy",
+              "rtScenePreprocess", "rtVisualizedSceneRaytrace", "rtVisualizedSceneDestroy", "rtVisualizedSceneToBitmap",
+              "rtBitmapCreate", "rtBitmapDestroy", "rtBitmapLoad", "rtBitmapSave", "rtGetErrorDesc"]:
+        assert hasattr(lib, n), n
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtgpuError) as e:
+        rt.Renderer(0)
+    assert e.value.code == 100
+
+
+@pytest.mark.parametrize("prefix,over", SCENES)
+def test_host_loader_matches_oracle_loader(prefix, over):
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    s = rt.Scene(os.path.join(ROOT, prefix), **over)
+    o = O.OracleScene(os.path.join(ROOT, prefix), **over)
+    v, sid = o.vertices()
+    assert np.array_equal(v.view(np.uint32), s.vertices().view(np.uint32))  # includes the loader's vertex nudge
+    assert np.array_equal(sid, s.sids())
+    assert (s.nt, s.ns, s.nl, s.npl) == (o.nt, o.ns, o.nl, o.npl)
+    assert (s.width, s.height) == (o.w, o.h) and s.gamma == o.gamma and s.desc.vmode == o.vmode
+
+
+def test_cfg_overrides_and_missing_files():
+    base = os.path.join(ROOT, "scenes/pokoj/s2")
+    assert rt.Scene(base, cfg=os.path.join(ROOT, "scenes/cegly.cfg")).gamma == 2.0
+    assert rt.Scene(base).gamma == 2.5  # no pokoj/s2.cfg: defaults stay (a warning in the reference)
+    assert rt.Scene(base, gamma=1.7).gamma == pytest.approx(1.7)
+    with pytest.raises(RuntimeError):
+        rt.Scene(os.path.join(ROOT, "scenes/nope/nope"))
+    with pytest.raises(RuntimeError):  # surface ids 10/20/30 need at least 31 surfaces
+        rt.Scene(os.path.join(ROOT, "scenes/test/s2"), atr=os.path.join(ROOT, "scenes/s3/s3.atr"))
+
+
+def test_texture_switch_follows_cwd_file(tmp_path):
+    cwd = os.getcwd()
+    try:
+        os.chdir(ROOT)
+        assert rt.Scene(os.path.join(ROOT, "scenes/pokoj/s2"), texture=True).desc.texture_present == 1
+        assert rt.Scene(os.path.join(ROOT, "scenes/pokoj/s2"), texture=False).desc.texture_present == 0
+        os.chdir(tmp_path)
+        assert rt.Scene(os.path.join(ROOT, "scenes/pokoj/s2"), texture=None).desc.texture_present == 0
+        with pytest.raises(RuntimeError):
+            rt.Scene(os.path.join(ROOT, "scenes/pokoj/s2"), texture=True)
+    finally:
+        os.chdir(cwd)
+
+
+def test_bmp_writer_bytes_match_oracle(tmp_path):
+    rng = np.random.default_rng(1)
+    for w, h in [(5, 3), (8, 8), (97, 61)]:  # widths with and without row padding
+        rgba = (rng.integers(0, 2 ** 32, size=(h, w), dtype=np.uint64) & 0xffffff00).astype(np.uint32)
+        p = str(tmp_path / "o.bmp")
+        rt.save_bmp24(rgba, p)
+        assert open(p, "rb").read() == O.bmp24(rgba)
+
+
+def test_cli_binary_prints_help():
+    import subprocess
+    out = subprocess.run([os.path.join(ROOT, "raytracer_amd", "raytrace")], capture_output=True, text=True)
+    assert out.returncode == 0 and "usage:" in out.stdout
