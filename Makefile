@@ -6,7 +6,8 @@ CC      ?= gcc
 ARCH    ?= gfx950
 PKG     := raytracer_amd
 # -ffp-contract=off: the trace path must round exactly like the reference's non-FMA binary32 code.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC
+# -fno-slp-vectorize: packed fp32 (v_pk_*) issues at half rate and needs register shuffles; plain ops are faster here.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC
 CFLAGS   := -O2 -std=gnu99 -ffp-contract=off -fPIC -Wall
 HOSTSRC  := $(PKG)/host/scene.c $(PKG)/host/bitmap.c $(PKG)/host/raytrace.c $(PKG)/host/error.c
 

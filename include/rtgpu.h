@@ -95,6 +95,9 @@ typedef struct rtgpu_counters {
   int64_t shadow_walks;    /* shadow queries that reached the grid walk */
   int64_t nearest_steps, nearest_tests; /* S and T of the nearest walks (only with option "count" = 1) */
   int64_t shadow_steps, shadow_tests;   /* S and T of the shadow walks   (only with option "count" = 1) */
+  /* SIMD efficiency of the two walk kernels (only with "count" = 1): triangle tests executed by
+   * active lanes / lane slots the wavefronts spent on them (64 per triangle iteration). */
+  int64_t nearest_lane_tests, nearest_lane_slots, shadow_lane_tests, shadow_lane_slots;
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP

@@ -54,7 +54,9 @@ class GridInfo(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("pixels", "pixels_traced", "nearest_queries", "shadow_queries", "shadow_walks",
-                                         "nearest_steps", "nearest_tests", "shadow_steps", "shadow_tests")]
+                                         "nearest_steps", "nearest_tests", "shadow_steps", "shadow_tests",
+                                         "nearest_lane_tests", "nearest_lane_slots", "shadow_lane_tests",
+                                         "shadow_lane_slots")]
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -95,7 +97,7 @@ def build_native(force=False):
 def gpu_lib():
     global _gpu
     if _gpu is None:
-        path = os.path.join(PKG, "librtgpu.so")
+        path = os.environ.get("RTGPU_LIB") or os.path.join(PKG, "librtgpu.so")  # RTGPU_LIB: kernel A/B experiments
         if not os.path.exists(path):
             raise RuntimeError("librtgpu.so is missing: run `make` (needs hipcc); there is no fallback path")
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)

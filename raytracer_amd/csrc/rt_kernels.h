@@ -8,10 +8,90 @@
 #include "rt_math.h"
 #include "rt_texture.h"
 
+#ifndef RT_SOURCE
+#define RT_SOURCE 1  // how a cell's triangle list reaches the lanes: 0 = scalar loads, 1 = LDS-staged batches
+#endif
+#ifndef RT_LDS_PIPELINE
+#define RT_LDS_PIPELINE 0
+#endif
+#ifndef RT_WAVES
+#define RT_WAVES 8  // waves per SIMD the two walk kernels are compiled for (caps their VGPR allocation)
+#endif
+
 namespace rt {
 
 RT_D int lane_id() { return threadIdx.x & 63; }
 RT_D unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
+
+// Streams the packed triangle list [beg, end) of one cell through every lane of the wavefront.
+// f(a, ab, ac, id, kt) is called once per record, in list order, with wave-uniform arguments;
+// more() is a wave-uniform predicate evaluated after each record (false = stop early).
+//
+// RT_SOURCE 1: the wavefront copies the list to its private LDS slice in batches of kBatch records with
+// coalesced 16-byte vector loads (64 lanes x 16 B = 21 records per instruction), then every lane reads the
+// same record back (LDS broadcast, two 16-byte reads + one 4-byte read per test; id and kt only on a hit).
+// LDS operations of one wavefront execute in issue order, so no barrier is needed between the copy and
+// the reads, nor before the next batch overwrites the slice.
+// RT_SOURCE 0: wave-uniform global loads (scalar cache path).
+constexpr int kBatch = 64;
+constexpr int kRecFloats = 12;
+using v4f = float __attribute__((ext_vector_type(4)));
+
+template <typename F, typename G>
+RT_D void stream_cell(const TriRec *__restrict__ recs, uint32_t beg, uint32_t end, float *slice, int lane, F &&f, G &&more) {
+#if RT_SOURCE == 1
+  for (uint32_t c0 = beg; c0 < end; c0 += kBatch) {
+    const int n = (int)(end - c0 < (uint32_t)kBatch ? end - c0 : (uint32_t)kBatch);
+    const int nvec = n * 3;
+    const float4 *src = reinterpret_cast<const float4 *>(recs + c0);
+    float4 *dst = reinterpret_cast<float4 *>(slice);
+    float4 v0, v1, v2;
+    if (lane < nvec) v0 = src[lane];
+    if (lane + 64 < nvec) v1 = src[lane + 64];
+    if (lane + 128 < nvec) v2 = src[lane + 128];
+    if (lane < nvec) dst[lane] = v0;
+    if (lane + 64 < nvec) dst[lane + 64] = v1;
+    if (lane + 128 < nvec) dst[lane + 128] = v2;
+    __builtin_amdgcn_wave_barrier();
+    // all nine floats of a record feed the branch-free part of the test, so the three reads
+    // (16 + 16 + 4 bytes, same address in every lane = LDS broadcast) sit together at the top
+#if RT_LDS_PIPELINE
+    v4f x = *reinterpret_cast<const v4f *>(slice);
+    v4f y = *reinterpret_cast<const v4f *>(slice + 4);
+    float z = slice[8];
+    for (int j = 0; j < n; ++j) {
+      const float *R = slice + j * kRecFloats;
+      const float *N = slice + (j + 1 < kBatch ? j + 1 : j) * kRecFloats;  // next record, read one test ahead
+      const v4f nx = *reinterpret_cast<const v4f *>(N);
+      const v4f ny = *reinterpret_cast<const v4f *>(N + 4);
+      const float nz = N[8];
+      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R);
+      if (!more()) return;
+      x = nx; y = ny; z = nz;
+    }
+#else
+    for (int j = 0; j < n; ++j) {
+      const float *R = slice + j * kRecFloats;
+      const v4f x = *reinterpret_cast<const v4f *>(R);
+      const v4f y = *reinterpret_cast<const v4f *>(R + 4);
+      const float z = R[8];
+      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R);
+      if (!more()) return;
+    }
+#endif
+    __builtin_amdgcn_wave_barrier();
+  }
+#else
+  for (uint32_t t = beg; t < end; ++t) {
+    const TriRec *T = recs + t;
+    f(ld3(T->a), ld3(T->ab), ld3(T->ac), reinterpret_cast<const float *>(T));
+    if (!more()) return;
+  }
+#endif
+}
+// id and kt of the record handed to f (read only when a test succeeds)
+RT_D int rec_id(const float *R) { return __float_as_int(R[9]); }
+RT_D float rec_kt(const float *R) { return R[10]; }
 
 // ------------------------------------------------------------------------------------------------
 // Per-triangle preprocess for one camera (preprocess.c:17-32): ij, ik, unit normal flipped towards
@@ -145,11 +225,6 @@ __global__ void __launch_bounds__(256) k_primary(CameraD cam, GridP g, int tile0
     st3(ry.r, dir);
     int i, j, k;
     if (startup_voxel(g, ob, dir, i, j, k)) { ry.i = i; ry.j = j; ry.k = k; } else ry.i = -1;
-    unsigned long long inside = __ballot(true), traced = __ballot(ry.i >= 0);
-    if (lane_id() == __ffsll(inside) - 1) {
-      atomicAdd(&ctl->stat[kPixels], (unsigned long long)__popcll(inside));
-      atomicAdd(&ctl->stat[kPixelsTraced], (unsigned long long)__popcll(traced));
-    }
   }
   rays[idx] = ry;
 }
@@ -166,13 +241,16 @@ __global__ void __launch_bounds__(256) k_primary(CameraD cam, GridP g, int tile0
 // next non-empty cell.  All triangles of a visited cell are tested (the reference's test ignores the
 // running minimum), and ties keep the lowest triangle index because lists are in ascending order.
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
+__global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
                                                  Ctl *__restrict__ ctl, int level) {
+  __shared__ __attribute__((aligned(16))) float lds_batches[4][kBatch * kRecFloats];
+  float *slice = lds_batches[threadIdx.x >> 6];
   const int lane = lane_id();
   const int nrays = ctl->count[level];
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
   unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0;
+  uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&ctl->ticket_nearest[level], 64u);
@@ -183,6 +261,8 @@ __global__ void __launch_bounds__(256) k_nearest(GridP g, const Ray *__restrict_
     ry.i = -2;
     if (idx < nrays) ry = rays[idx];
     bool alive = ry.i >= 0;
+    nPixels += __popcll(__ballot(ry.i != -2));
+    nTraced += __popcll(__ballot(alive));
     const f3 o = ld3(ry.o), r = ld3(ry.r);
     Hit h;
     h.tri = alive ? -1 : -2;
@@ -214,15 +294,18 @@ __global__ void __launch_bounds__(256) k_nearest(GridP g, const Ray *__restrict_
       int best_id = -1;
       float best_u = 0.0f, best_v = 0.0f;
       if (COUNT) { nWave += (unsigned long long)(end - beg); if (in) nLane += end - beg; }
-      for (uint32_t t = beg; t < end; ++t) {
-        const TriRec *T = recs + t;
-        if (in) {
-          float d, u, v;
-          if (tri_test(ld3(T->a), ld3(T->ab), ld3(T->ac), o, r, d, u, v)) {
-            if (T->id != ry.current && d < best) { best = d; best_id = T->id; best_u = u; best_v = v; }
-          }
-        }
-      }
+      stream_cell(recs, beg, end, slice, lane,
+                  [&](f3 ta, f3 tab, f3 tac, const float *R) {
+                    float det, tp; f3 tv;
+                    if (tri_candidate(ta, tab, tac, o, r, det, tp, tv) & in) {
+                      float d, u, v;
+                      if (tri_exact(tab, tac, r, det, tp, tv, d, u, v)) {
+                        const int id = rec_id(R);
+                        if (id != ry.current && d < best) { best = d; best_id = id; best_u = u; best_v = v; }
+                      }
+                    }
+                  },
+                  [] { return true; });
       if (in) {
         if (best_id >= 0) {
           h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v; h.i = w.i; h.j = w.j; h.k = w.k;
@@ -240,6 +323,14 @@ __global__ void __launch_bounds__(256) k_nearest(GridP g, const Ray *__restrict_
       }
     }
     if (idx < nrays) hits[idx] = h;
+    nHits += __popcll(__ballot(h.tri >= 0));
+  }
+  if (lane == 0) {
+    if (level == 0) {
+      atomicAdd(&ctl->stat[kPixels], (unsigned long long)nPixels);
+      atomicAdd(&ctl->stat[kPixelsTraced], (unsigned long long)nTraced);
+    }
+    atomicAdd(&ctl->stat[kShaded], (unsigned long long)nHits);
   }
   if (COUNT) {
     // wave-level sums, one atomic per counter per wavefront
@@ -293,10 +384,6 @@ __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__re
       if (sf.kr > 0.0f) { want_refl = true; refl_dir = reflect3(norm, inv, dot3(norm, inv)); }
       if (sf.kt > 0.0f) { want_refr = true; refr_dir = refract3(norm, inv, sf.eta); }
     }
-  }
-  {
-    unsigned long long sh = __ballot(h.tri >= 0);
-    if (sh != 0 && lane == __ffsll(sh) - 1) atomicAdd(&ctl->stat[kShaded], (unsigned long long)__popcll(sh));
   }
   // append children (uniform control flow from here on)
 #pragma unroll
@@ -388,15 +475,17 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 // transparency product ts (>= 0) if the light is visible, -1 if the point is in shadow.
 // The reference's per-triangle shadow cache (voxelize.c:647-655) is scan-order state; it is dropped.
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_shadow(GridP g, ShadeP sp, const Node *__restrict__ nodes,
+__global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const Node *__restrict__ nodes,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
                                                 Ctl *__restrict__ ctl, int level, int node_base) {
+  __shared__ __attribute__((aligned(16))) float lds_batches[4][kBatch * kRecFloats];
+  float *slice = lds_batches[threadIdx.x >> 6];
   const int lane = lane_id();
   const int n = ctl->count[level];
   const long long total = (long long)n * sp.nslots;
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
-  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0;
+  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0;
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&ctl->ticket_shadow[level], 64u);
@@ -455,22 +544,23 @@ __global__ void __launch_bounds__(256) k_shadow(GridP g, ShadeP sp, const Node *
       const int cell = __builtin_amdgcn_readlane(mycell, leader);
       const uint32_t beg = cstart[cell], end = cstart[cell + 1];
       bool in = alive && mycell == cell;
-      for (uint32_t t = beg; t < end; ++t) {
-        const TriRec *T = recs + t;
-        if (in) {
-          float d, u, v;
-          if (tri_test(ld3(T->a), ld3(T->ab), ld3(T->ac), a, r, d, u, v)) {
-            if (T->id != current) {
-              if (T->kt > 0.0f) {
-                ts *= T->kt;  // every listing of a transparent triangle attenuates (:703-706)
-              } else if (d > 0.00001f && d < dmax) {
-                result = -1.0f; alive = false; in = false;  // opaque blocker (:707-711)
-              }
-            }
-          }
-        }
-        if (__ballot(in) == 0) break;
-      }
+      stream_cell(recs, beg, end, slice, lane,
+                  [&](f3 ta, f3 tab, f3 tac, const float *R) {
+                    if (COUNT) { nWave++; if (in) nLane++; }
+                    float det, tp; f3 tv;
+                    if (tri_candidate(ta, tab, tac, a, r, det, tp, tv) & in) {
+                      float d, u, v;
+                      if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
+                        const float kt = rec_kt(R);
+                        if (kt > 0.0f) {
+                          ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
+                        } else if (d > 0.00001f && d < dmax) {
+                          result = -1.0f; alive = false; in = false;  // opaque blocker (:707-711)
+                        }
+                      }
+                    }
+                  },
+                  [&] { return __ballot(in) != 0; });
       if (in) {
         for (;;) {
           dda_step(w);
@@ -487,8 +577,10 @@ __global__ void __launch_bounds__(256) k_shadow(GridP g, ShadeP sp, const Node *
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       nS += __shfl_down(nS, off); nT += __shfl_down(nT, off); nQ += __shfl_down(nQ, off); nW += __shfl_down(nW, off);
+      nLane += __shfl_down(nLane, off);
     }
     if (lane == 0) {
+      atomicAdd(&ctl->stat[kShadLaneTests], nLane); atomicAdd(&ctl->stat[kShadWaveTests], nWave * 64ull);
       atomicAdd(&ctl->stat[kShadS], nS); atomicAdd(&ctl->stat[kShadT], nT);
       atomicAdd(&ctl->stat[kShadowQ], nQ); atomicAdd(&ctl->stat[kShadowWalks], nW);
     }

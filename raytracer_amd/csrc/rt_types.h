@@ -92,6 +92,6 @@ struct Ctl {
   unsigned long long stat[16];
 };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
-            kNearLaneTests, kNearWaveTests, kShaded, kStatCount };
+            kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests, kStatCount };
 
 }  // namespace rt

@@ -556,6 +556,8 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   out->shadow_walks = (int64_t)h[kShadowWalks];
   out->nearest_steps = (int64_t)h[kNearS]; out->nearest_tests = (int64_t)h[kNearT];
   out->shadow_steps = (int64_t)h[kShadS]; out->shadow_tests = (int64_t)h[kShadT];
+  out->nearest_lane_tests = (int64_t)h[kNearLaneTests]; out->nearest_lane_slots = (int64_t)h[kNearWaveTests];
+  out->shadow_lane_tests = (int64_t)h[kShadLaneTests]; out->shadow_lane_slots = (int64_t)h[kShadWaveTests];
   return RTGPU_OK;
 }
 
