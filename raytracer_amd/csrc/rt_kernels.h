@@ -93,6 +93,43 @@ RT_D void stream_cell(const TriRec *__restrict__ recs, uint32_t beg, uint32_t en
 RT_D int rec_id(const float *R) { return __float_as_int(R[9]); }
 RT_D float rec_kt(const float *R) { return R[10]; }
 
+// One lane's own record fetch (per-lane and one-ray-per-wave modes): 16 + 16 + 4 bytes from L1/L2.
+RT_D const float *load_rec(const TriRec *__restrict__ recs, uint32_t idx, f3 &a, f3 &ab, f3 &ac) {
+  const float *R = reinterpret_cast<const float *>(recs + idx);
+  const v4f x = *reinterpret_cast<const v4f *>(R);
+  const v4f y = *reinterpret_cast<const v4f *>(R + 4);
+  const float z = R[8];
+  a = mk3(x.x, x.y, x.z); ab = mk3(x.w, y.x, y.y); ac = mk3(y.z, y.w, z);
+  return R;
+}
+RT_D float lane_bcast(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+RT_D f3 lane_bcast3(f3 v, int l) { return mk3(lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)); }
+
+// How a wavefront spends its lanes on triangle tests.  Three modes, chosen per step from what its
+// unfinished rays are standing in (all give the reference's result for every ray; only the order in
+// which independent tests are evaluated differs):
+//   cell mode  many rays share one cell: the cell's list is staged in LDS once, every ray of the cell
+//              tests every triangle (1 lane = 1 ray).  Coherent rays, any list length.
+//   lane mode  rays scattered over many short lists: every lane walks its own list from L1/L2.
+//   ray mode   a ray alone in a long list: the 64 lanes test 64 different triangles for that one ray
+//              and the winner is found with a cross-lane reduction.
+#ifndef RT_CELL_MIN_GROUP
+#define RT_CELL_MIN_GROUP 32  // rays sharing the leader's cell from which cell mode is taken unconditionally
+#endif
+#ifndef RT_SHORT_LIST
+#define RT_SHORT_LIST 32      // lists up to this length are walked in lane mode
+#endif
+#ifndef RT_LANE_MIN
+#define RT_LANE_MIN 8         // lane mode needs at least this many rays with short lists
+#endif
+enum WalkMode { kCellMode = 0, kLaneMode = 1, kRayMode = 2 };
+RT_D int pick_mode(int group, uint32_t leader_cnt, int short_lanes) {
+  if (group >= RT_CELL_MIN_GROUP) return kCellMode;
+  if (short_lanes >= RT_LANE_MIN) return kLaneMode;
+  // the leader's group alone: cell mode costs cnt steps, ray mode group * (ceil(cnt/64) + 1 for the reduction)
+  return leader_cnt <= (uint32_t)group * ((leader_cnt + 63u) / 64u + 1u) ? kCellMode : kRayMode;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-triangle preprocess for one camera (preprocess.c:17-32): ij, ik, unit normal flipped towards
 // the observer, plane offset d.  geom: 9 floats (i, ij, ik); aux: 4 floats (n, d).
@@ -269,44 +306,100 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     h.d = h.u = h.v = 0.0f; h.i = h.j = h.k = 0; h.pad = 0;
     Dda w;
     int mycell = 0;
+    uint32_t mybeg = 0, mycnt = 0;  // triangle list of mycell
     if (alive) {
       if (COUNT) nQ++;
       dda_init(g, o, r, ry.i, ry.j, ry.k, w);
       // stand on the first non-empty cell of the walk (the start voxel counts as visited)
       for (;;) {
         mycell = cell_index(g, w.i, w.j, w.k);
-        uint32_t b = cstart[mycell], e = cstart[mycell + 1];
-        if (COUNT) { nS++; nT += e - b; }
-        if (e > b) break;
+        mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+        if (COUNT) { nS++; nT += mycnt; }
+        if (mycnt > 0) break;
         dda_step(w);
         if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
       }
     }
     for (;;) {
-      unsigned long long m = __ballot(alive);
+      const unsigned long long m = __ballot(alive);
       if (m == 0) break;
       const int leader = __ffsll(m) - 1;
       const int cell = __builtin_amdgcn_readlane(mycell, leader);
-      const uint32_t beg = cstart[cell], end = cstart[cell + 1];
-      const bool in = alive && mycell == cell;
+      const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
+      const bool in_group = alive && mycell == cell;
+      const bool is_short = alive && mycnt <= RT_SHORT_LIST;
+      const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       // exit distance of this voxel: a hit only counts if it lies before it (voxelize.c:569,574)
       float best = min3_ref(w.tx + w.dtx, w.ty + w.dty, w.tz + w.dtz);
       int best_id = -1;
       float best_u = 0.0f, best_v = 0.0f;
-      if (COUNT) { nWave += (unsigned long long)(end - beg); if (in) nLane += end - beg; }
-      stream_cell(recs, beg, end, slice, lane,
-                  [&](f3 ta, f3 tab, f3 tac, const float *R) {
-                    float det, tp; f3 tv;
-                    if (tri_candidate(ta, tab, tac, o, r, det, tp, tv) & in) {
-                      float d, u, v;
-                      if (tri_exact(tab, tac, r, det, tp, tv, d, u, v)) {
-                        const int id = rec_id(R);
-                        if (id != ry.current && d < best) { best = d; best_id = id; best_u = u; best_v = v; }
+      bool proc;  // this lane's current cell is fully tested after this step
+      if (mode == kCellMode) {
+        proc = in_group;
+        if (COUNT) { nWave += (unsigned long long)cnt; if (proc) nLane += cnt; }
+        stream_cell(recs, beg, beg + cnt, slice, lane,
+                    [&](f3 ta, f3 tab, f3 tac, const float *R) {
+                      float det, tp; f3 tv;
+                      if (tri_candidate(ta, tab, tac, o, r, det, tp, tv) & proc) {
+                        float d, u, v;
+                        if (tri_exact(tab, tac, r, det, tp, tv, d, u, v)) {
+                          const int id = rec_id(R);
+                          if (id != ry.current && d < best) { best = d; best_id = id; best_u = u; best_v = v; }
+                        }
                       }
-                    }
-                  },
-                  [] { return true; });
-      if (in) {
+                    },
+                    [] { return true; });
+      } else if (mode == kLaneMode) {
+        proc = is_short;
+        const uint32_t pn = proc ? mycnt : 0u;
+        for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
+          if (COUNT) { nWave++; if (i < pn) nLane++; }
+          if (i < pn) {
+            f3 ta, tab, tac; float det, tp; f3 tv;
+            const float *R = load_rec(recs, mybeg + i, ta, tab, tac);
+            if (tri_candidate(ta, tab, tac, o, r, det, tp, tv)) {
+              float d, u, v;
+              if (tri_exact(tab, tac, r, det, tp, tv, d, u, v)) {
+                const int id = rec_id(R);
+                if (id != ry.current && d < best) { best = d; best_id = id; best_u = u; best_v = v; }
+              }
+            }
+          }
+        }
+      } else {
+        // ray mode: the leader's ray against 64 triangles per step; lane L takes list positions L, L+64, ...
+        proc = lane == leader;
+        const f3 lo = lane_bcast3(o, leader), lr = lane_bcast3(r, leader);
+        const int lcur = __builtin_amdgcn_readlane(ry.current, leader);
+        float cb = lane_bcast(best, leader), cu = 0.0f, cv = 0.0f;
+        int cid = -1;
+        uint32_t cpos = 0xffffffffu;
+        for (uint32_t t0 = beg; t0 < beg + cnt; t0 += 64) {
+          const uint32_t t = t0 + lane;
+          if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
+          if (t < beg + cnt) {
+            f3 ta, tab, tac; float det, tp; f3 tv;
+            const float *R = load_rec(recs, t, ta, tab, tac);
+            if (tri_candidate(ta, tab, tac, lo, lr, det, tp, tv)) {
+              float d, u, v;
+              if (tri_exact(tab, tac, lr, det, tp, tv, d, u, v)) {
+                const int id = rec_id(R);
+                if (id != lcur && d < cb) { cb = d; cpos = t; cid = id; cu = u; cv = v; }  // ascending t: earliest wins in a lane
+              }
+            }
+          }
+        }
+        // smallest d, ties to the earliest list position: the reference's strict `d < dmin` scan order
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const float od = __shfl_xor(cb, off), ou = __shfl_xor(cu, off), ov = __shfl_xor(cv, off);
+          const uint32_t op = __shfl_xor(cpos, off);
+          const int oi = __shfl_xor(cid, off);
+          if (od < cb || (od == cb && op < cpos)) { cb = od; cpos = op; cid = oi; cu = ou; cv = ov; }
+        }
+        if (proc) { best = cb; best_id = cid; best_u = cu; best_v = cv; }
+      }
+      if (proc) {
         if (best_id >= 0) {
           h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v; h.i = w.i; h.j = w.j; h.k = w.k;
           alive = false;
@@ -315,9 +408,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
             dda_step(w);
             if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
             mycell = cell_index(g, w.i, w.j, w.k);
-            uint32_t b = cstart[mycell], e = cstart[mycell + 1];
-            if (COUNT) { nS++; nT += e - b; }
-            if (e > b) break;
+            mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+            if (COUNT) { nS++; nT += mycnt; }
+            if (mycnt > 0) break;
           }
         }
       }
@@ -500,6 +593,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     Dda w;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int mycell = 0;
+    uint32_t mybeg = 0, mycnt = 0;  // triangle list of mycell
     if (item < total) {
       slot = (int)(item / n);
       nidx = (int)(item - (long long)slot * n);
@@ -527,9 +621,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
             if (COUNT) nW++;
             for (;;) {
               mycell = cell_index(g, w.i, w.j, w.k);
-              uint32_t bb = cstart[mycell], ee = cstart[mycell + 1];
-              if (COUNT) { nS++; nT += ee - bb; }
-              if (ee > bb) break;
+              mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+              if (COUNT) { nS++; nT += mycnt; }
+              if (mycnt > 0) break;
               dda_step(w);
               if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
             }
@@ -538,37 +632,97 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       }
     }
     for (;;) {
-      unsigned long long m = __ballot(alive);
+      const unsigned long long m = __ballot(alive);
       if (m == 0) break;
       const int leader = __ffsll(m) - 1;
       const int cell = __builtin_amdgcn_readlane(mycell, leader);
-      const uint32_t beg = cstart[cell], end = cstart[cell + 1];
-      bool in = alive && mycell == cell;
-      stream_cell(recs, beg, end, slice, lane,
-                  [&](f3 ta, f3 tab, f3 tac, const float *R) {
-                    if (COUNT) { nWave++; if (in) nLane++; }
-                    float det, tp; f3 tv;
-                    if (tri_candidate(ta, tab, tac, a, r, det, tp, tv) & in) {
-                      float d, u, v;
-                      if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
-                        const float kt = rec_kt(R);
-                        if (kt > 0.0f) {
-                          ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
-                        } else if (d > 0.00001f && d < dmax) {
-                          result = -1.0f; alive = false; in = false;  // opaque blocker (:707-711)
+      const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
+      const bool in_group = alive && mycell == cell;
+      const bool is_short = alive && mycnt <= RT_SHORT_LIST;
+      const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
+      bool proc;  // this lane's current cell is fully tested (or the ray blocked) after this step
+      if (mode == kCellMode) {
+        proc = in_group;
+        bool in = in_group;
+        stream_cell(recs, beg, beg + cnt, slice, lane,
+                    [&](f3 ta, f3 tab, f3 tac, const float *R) {
+                      if (COUNT) { nWave++; if (in) nLane++; }
+                      float det, tp; f3 tv;
+                      if (tri_candidate(ta, tab, tac, a, r, det, tp, tv) & in) {
+                        float d, u, v;
+                        if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
+                          const float kt = rec_kt(R);
+                          if (kt > 0.0f) {
+                            ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
+                          } else if (d > 0.00001f && d < dmax) {
+                            result = -1.0f; alive = false; in = false;  // opaque blocker (:707-711)
+                          }
                         }
                       }
-                    }
-                  },
-                  [&] { return __ballot(in) != 0; });
-      if (in) {
+                    },
+                    [&] { return __ballot(in) != 0; });
+      } else if (mode == kLaneMode) {
+        proc = is_short;
+        uint32_t pn = proc ? mycnt : 0u;
+        for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
+          if (COUNT) { nWave++; if (i < pn) nLane++; }
+          if (i < pn) {
+            f3 ta, tab, tac; float det, tp; f3 tv;
+            const float *R = load_rec(recs, mybeg + i, ta, tab, tac);
+            if (tri_candidate(ta, tab, tac, a, r, det, tp, tv)) {
+              float d, u, v;
+              if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
+                const float kt = rec_kt(R);
+                if (kt > 0.0f) {
+                  ts *= kt;
+                } else if (d > 0.00001f && d < dmax) {
+                  result = -1.0f; alive = false; pn = 0u;
+                }
+              }
+            }
+          }
+        }
+      } else {
+        // ray mode: the leader's shadow ray against 64 triangles per step
+        proc = lane == leader;
+        const f3 la = lane_bcast3(a, leader), lr = lane_bcast3(r, leader);
+        const int lcur = __builtin_amdgcn_readlane(current, leader);
+        const float ldmax = lane_bcast(dmax, leader);
+        float cts = lane_bcast(ts, leader);
+        bool blocked = false;
+        for (uint32_t t0 = beg; t0 < beg + cnt && !blocked; t0 += 64) {
+          const uint32_t t = t0 + lane;
+          if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
+          bool transparent = false, opaque = false;
+          float kt = 0.0f;
+          if (t < beg + cnt) {
+            f3 ta, tab, tac; float det, tp; f3 tv;
+            const float *R = load_rec(recs, t, ta, tab, tac);
+            if (tri_candidate(ta, tab, tac, la, lr, det, tp, tv)) {
+              float d, u, v;
+              if (tri_exact(tab, tac, lr, det, tp, tv, d, u, v) && rec_id(R) != lcur) {
+                kt = rec_kt(R);
+                if (kt > 0.0f) transparent = true;
+                else if (d > 0.00001f && d < ldmax) opaque = true;
+              }
+            }
+          }
+          // the transparency product is taken in list order, like the reference's scan
+          for (unsigned long long tm = __ballot(transparent); tm != 0; tm &= tm - 1) cts *= lane_bcast(kt, __ffsll(tm) - 1);
+          blocked = __ballot(opaque) != 0;
+        }
+        if (proc) {
+          if (blocked) { result = -1.0f; alive = false; } else ts = cts;
+        }
+      }
+      if (proc && alive) {
         for (;;) {
           dda_step(w);
           if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
           mycell = cell_index(g, w.i, w.j, w.k);
-          uint32_t bb = cstart[mycell], ee = cstart[mycell + 1];
-          if (COUNT) { nS++; nT += ee - bb; }
-          if (ee > bb) break;
+          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+          if (COUNT) { nS++; nT += mycnt; }
+          if (mycnt > 0) break;
         }
       }
     }
