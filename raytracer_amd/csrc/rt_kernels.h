@@ -14,6 +14,9 @@
 #ifndef RT_LDS_PIPELINE
 #define RT_LDS_PIPELINE 0
 #endif
+#ifndef RT_UNROLL
+#define RT_UNROLL 2
+#endif
 #ifndef RT_WAVES
 #define RT_WAVES 8  // waves per SIMD the two walk kernels are compiled for (caps their VGPR allocation)
 #endif
@@ -24,7 +27,7 @@ RT_D int lane_id() { return threadIdx.x & 63; }
 RT_D unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
 // Streams the packed triangle list [beg, end) of one cell through every lane of the wavefront.
-// f(a, ab, ac, id, kt) is called once per record, in list order, with wave-uniform arguments;
+// f(a, ab, ac, record, index) is called once per record, in list order, with wave-uniform arguments;
 // more() is a wave-uniform predicate evaluated after each record (false = stop early).
 //
 // RT_SOURCE 1: the wavefront copies the list to its private LDS slice in batches of kBatch records with
@@ -65,17 +68,18 @@ RT_D void stream_cell(const TriRec *__restrict__ recs, uint32_t beg, uint32_t en
       const v4f nx = *reinterpret_cast<const v4f *>(N);
       const v4f ny = *reinterpret_cast<const v4f *>(N + 4);
       const float nz = N[8];
-      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R);
+      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R, c0 + (uint32_t)j);
       if (!more()) return;
       x = nx; y = ny; z = nz;
     }
 #else
+#pragma unroll RT_UNROLL
     for (int j = 0; j < n; ++j) {
       const float *R = slice + j * kRecFloats;
       const v4f x = *reinterpret_cast<const v4f *>(R);
       const v4f y = *reinterpret_cast<const v4f *>(R + 4);
       const float z = R[8];
-      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R);
+      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R, c0 + (uint32_t)j);
       if (!more()) return;
     }
 #endif
@@ -84,7 +88,7 @@ RT_D void stream_cell(const TriRec *__restrict__ recs, uint32_t beg, uint32_t en
 #else
   for (uint32_t t = beg; t < end; ++t) {
     const TriRec *T = recs + t;
-    f(ld3(T->a), ld3(T->ab), ld3(T->ac), reinterpret_cast<const float *>(T));
+    f(ld3(T->a), ld3(T->ab), ld3(T->ac), reinterpret_cast<const float *>(T), t);
     if (!more()) return;
   }
 #endif
@@ -337,10 +341,11 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       if (mode == kCellMode) {
         proc = in_group;
         if (COUNT) { nWave += (unsigned long long)cnt; if (proc) nLane += cnt; }
+        const f3 rr = proc ? r : mk3(0.0f, 0.0f, 0.0f);  // lanes outside the cell test with r = 0: never a candidate
         stream_cell(recs, beg, beg + cnt, slice, lane,
-                    [&](f3 ta, f3 tab, f3 tac, const float *R) {
+                    [&](f3 ta, f3 tab, f3 tac, const float *R, uint32_t) {
                       float det, tp; f3 tv;
-                      if (tri_candidate(ta, tab, tac, o, r, det, tp, tv) & proc) {
+                      if (tri_candidate(ta, tab, tac, o, rr, det, tp, tv)) {
                         float d, u, v;
                         if (tri_exact(tab, tac, r, det, tp, tv, d, u, v)) {
                           const int id = rec_id(R);
@@ -644,23 +649,28 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       if (mode == kCellMode) {
         proc = in_group;
         bool in = in_group;
-        stream_cell(recs, beg, beg + cnt, slice, lane,
-                    [&](f3 ta, f3 tab, f3 tac, const float *R) {
-                      if (COUNT) { nWave++; if (in) nLane++; }
-                      float det, tp; f3 tv;
-                      if (tri_candidate(ta, tab, tac, a, r, det, tp, tv) & in) {
-                        float d, u, v;
-                        if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
-                          const float kt = rec_kt(R);
-                          if (kt > 0.0f) {
-                            ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
-                          } else if (d > 0.00001f && d < dmax) {
-                            result = -1.0f; alive = false; in = false;  // opaque blocker (:707-711)
-                          }
-                        }
-                      }
-                    },
-                    [&] { return __ballot(in) != 0; });
+        f3 rr = in ? r : mk3(0.0f, 0.0f, 0.0f);  // lanes outside the cell, and blocked ones, test with r = 0
+        auto test = [&](f3 ta, f3 tab, f3 tac, const float *R, uint32_t) {
+          float det, tp; f3 tv;
+          if (tri_candidate(ta, tab, tac, a, rr, det, tp, tv)) {
+            float d, u, v;
+            if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
+              const float kt = rec_kt(R);
+              if (kt > 0.0f) {
+                ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
+              } else if (d > 0.00001f && d < dmax) {
+                result = -1.0f; alive = false; in = false; rr = mk3(0.0f, 0.0f, 0.0f);  // opaque blocker (:707-711)
+              }
+            }
+          }
+        };
+        if (__ballot(in) != 0)
+          stream_cell(recs, beg, beg + cnt, slice, lane,
+                      [&](f3 ta, f3 tab, f3 tac, const float *R, uint32_t pos) {
+                        if (COUNT) { nWave++; if (in) nLane++; }
+                        test(ta, tab, tac, R, pos);
+                      },
+                      [&] { return __ballot(in) != 0; });
       } else if (mode == kLaneMode) {
         proc = is_short;
         uint32_t pn = proc ? mycnt : 0u;

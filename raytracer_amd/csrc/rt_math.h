@@ -169,30 +169,31 @@ RT_D bool tri_test(f3 a, f3 ab, f3 ac, f3 o, f3 r, float &d, float &u, float &v)
 //
 // tri_candidate: p, det, tv and tp = tv.p exactly as intersection.c:62-70 computes them, then a conservative
 // range check of u = tp/det that needs no division:  u in [0,1]  <=>  |2 tp - det| <= |det|.
-// With w = |fma(2, tp, -det)| (one rounding) the triangle is rejected when w > 1.00002 |det|, i.e. when the
+// With w = |fma(2, tp, -det)| (one rounding) the triangle is rejected when w >= 1.00002 |det|, i.e. when the
 // real quotient tp/det is outside [-9.9e-6, 1.0000099]; the reference's u = fl(tp * fl(1/det)) is within
 // 3e-7 relative of that quotient, so it is then outside [0,1] as well (and nowhere near the underflow that
-// would turn a tiny negative u into -0).  Most triangles of a cell are nowhere near the ray and end here,
-// without the correctly rounded division and without a branch.  A NaN (NaN ray direction after total
-// internal reflection) is never rejected here, as in the reference.
+// would turn a tiny negative u into -0).  det = 0 is rejected too (w >= 0), as the reference's |det| < 1e-6
+// test would; a tiny non-zero det with u in range survives and meets that test in tri_exact.  Most
+// triangles of a cell are nowhere near the ray and end here, without the correctly rounded division and
+// without a branch.  A NaN (NaN ray direction after total internal reflection) is never rejected here, as
+// in the reference.  A lane that must not take part passes r = 0: det = tp = 0, rejected.
 RT_D bool tri_candidate(f3 a, f3 ab, f3 ac, f3 o, f3 r, float &det, float &tp, f3 &tv) {
   f3 p = cross3(r, ac);
   det = dot3(ab, p);
   tv = sub3(o, a);
   tp = dot3(tv, p);
-  const float ad = __builtin_fabsf(det);
   const float w = __builtin_fabsf(__builtin_fmaf(2.0f, tp, -det));
-  // bitwise, not short-circuit: one compare chain, no control flow
-  return !(ad < 0.000001f) & !(w > ad * 1.00002f);
+  return !(w >= __builtin_fabsf(det) * 1.00002f);
 }
-// tri_exact: intersection.c:68-83 from the division on, for the survivors; no early exits (it is rare).
+// tri_exact: intersection.c:64-83 from the determinant test on, for the survivors; no early exits (it is rare).
 RT_D bool tri_exact(f3 ab, f3 ac, f3 r, float det, float tp, f3 tv, float &d, float &u, float &v) {
   float inv = 1.0f / det;
   u = tp * inv;
   f3 q = cross3(tv, ab);
   v = dot3(r, q) * inv;
   d = dot3(ac, q) * inv;
-  return !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(d < 0.0f);
+  // bitwise, not short-circuit: one compare chain, no control flow
+  return !((det > -0.000001f) & (det < 0.000001f)) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(d < 0.0f);
 }
 
 // float -> uint32_t as the reference binary converts the tone-mapped channel (64-bit cvttss2si, low
