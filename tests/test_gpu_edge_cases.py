@@ -1,0 +1,179 @@
+"""Edge cases of the GPU trace path, all through the C ABI and all against the CPU oracle or the
+reference's own digests: ragged image sizes, empty light sets, the three voxelisation modes, chunked
+queues, idempotence, error codes, and the C command line end to end."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd.api import rgba_to_u8
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KNOWN = json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    os.chdir(ROOT)
+    r = rt.Renderer(0)
+    yield r
+    r.close()
+
+
+def both(renderer, prefix, w, h, **over):
+    scene = rt.Scene(prefix, width=w, height=h, **over)
+    renderer.upload(scene)
+    renderer.frame_begin()
+    g = renderer.render_host()
+    o = O.OracleScene(prefix, width=w, height=h, **over).render(shadow_cache=False)
+    return scene, g, o
+
+
+def assert_same(g, o):
+    assert np.array_equal(g["ids"], o["ids"])
+    assert np.array_equal(g["rgb"].view(np.uint32), o["rgb"].view(np.uint32)) or np.allclose(g["rgb"], o["rgb"], rtol=1e-5, atol=0)
+    assert np.allclose(g["minmax"], o["minmax"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (9, 17), (64, 8), (65, 9)])
+def test_ragged_image_sizes(renderer, w, h):
+    _, g, o = both(renderer, os.path.join(ROOT, "scenes/s3/s3"), w, h)
+    assert_same(g, o)
+
+
+def test_rays_that_never_enter_the_grid_leave_pixels_untouched(renderer):
+    """scenes/test: 31 % of the primary rays miss the domain; those pixels stay 0 and out of min/max."""
+    over = {"atr": os.path.join(ROOT, "scenes/temple/temple.atr")}
+    _, g, o = both(renderer, os.path.join(ROOT, "scenes/test/s2"), 200, 150, **over)
+    assert_same(g, o)
+    assert (g["ids"] < 0).sum() > 0.5 * g["ids"].size
+
+
+def test_no_lights(renderer, tmp_path):
+    """A missing .lgt is only a warning in the reference: nl = 0, ambient and secondary rays only."""
+    _, g, o = both(renderer, os.path.join(ROOT, "scenes/s3/s3"), 80, 60, lgt=str(tmp_path / "none.lgt"))
+    assert_same(g, o)
+
+
+@pytest.mark.parametrize("cfg_text", ["voxmode FIXED voxparams 5 4 6\n", "voxmode MODIFIED_DEFAULT voxparams 0.5 2 1.5\n",
+                                      "gamma 1.8 distmod 3.5 voxmode DEFAULT voxparams 1 1 1\n"])
+def test_voxelisation_modes_and_config_keys(renderer, tmp_path, cfg_text):
+    cfg = tmp_path / "r.cfg"
+    cfg.write_text(cfg_text)
+    prefix = os.path.join(ROOT, "scenes/pokoj/s2")
+    scene, g, o = both(renderer, prefix, 96, 72, cfg=str(cfg))
+    assert_same(g, o)
+    og = O.OracleScene(prefix, width=96, height=72, cfg=str(cfg))
+    og.render(shadow_cache=False, rows=(0, 1))
+    gg, ogr = renderer.grid(), og.grid()
+    assert np.array_equal(gg["nv"], ogr["nv"]) and np.array_equal(gg["refs"], ogr["refs"])
+
+
+def test_invalid_voxel_coefficients_are_rejected_like_the_reference(renderer, tmp_path):
+    cfg = tmp_path / "bad.cfg"
+    cfg.write_text("voxmode FIXED voxparams 4 0 4\n")
+    scene = rt.Scene(os.path.join(ROOT, "scenes/s3/s3"), width=32, height=24, cfg=str(cfg))
+    renderer.upload(scene)
+    with pytest.raises(rt.RtgpuError) as e:
+        renderer.frame_begin()
+    assert e.value.code == 7  # E_INVALID_PARAM_VALUE
+
+
+def test_chunked_queues_give_the_same_frame(renderer):
+    """A tiny queue budget cuts the frame into many chunks of tiles (secondary rays included)."""
+    prefix = os.path.join(ROOT, "scenes/pokoj/s2")
+    scene = rt.Scene(prefix, width=200, height=150)
+    renderer.upload(scene)
+    renderer.frame_begin()
+    whole = renderer.render_host()
+    renderer.set_option("chunk_bytes", 2 << 20)
+    try:
+        renderer.frame_begin()
+        parts = renderer.render_host()
+    finally:
+        renderer.set_option("chunk_bytes", 8 << 30)
+    assert np.array_equal(whole["ids"], parts["ids"])
+    assert np.array_equal(whole["rgb"].view(np.uint32), parts["rgb"].view(np.uint32))
+    assert np.array_equal(whole["minmax"], parts["minmax"])
+
+
+def test_frames_are_idempotent_and_independent_of_the_persistent_grid_size(renderer):
+    prefix = os.path.join(ROOT, "scenes/s5/s5")
+    scene = rt.Scene(prefix, width=160, height=120)
+    renderer.upload(scene)
+    renderer.frame_begin()
+    a = renderer.render_host()
+    renderer.frame_begin()  # the reference would grow the domain again here; the GPU library does not
+    b = renderer.render_host()
+    renderer.set_option("waves_per_cu", 4)
+    try:
+        c = renderer.render_host()
+    finally:
+        renderer.set_option("waves_per_cu", 32)
+    for other in (b, c):
+        assert np.array_equal(a["ids"], other["ids"])
+        assert np.array_equal(a["rgb"].view(np.uint32), other["rgb"].view(np.uint32))
+
+
+def test_planar_lights_refuse_more_than_one_rank(renderer):
+    import torch
+    scene = rt.Scene(os.path.join(ROOT, "scenes/s2/s2"), width=32, height=24)
+    renderer.upload(scene)
+    renderer.frame_begin()
+    n = renderer.tile_count(0, 2) * 64
+    rgb = torch.zeros(n * 3, device="cuda"); ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+    mm = torch.zeros(6, device="cuda")
+    with pytest.raises(rt.RtgpuError) as e:
+        renderer.render(rgb, ids, mm, 0, 2)
+    assert e.value.code == 102
+
+
+@pytest.mark.parametrize("name", ["s3", "temple", "ulica", "test"])
+def test_native_resolution_bmp_matches_reference_digest(renderer, name, tmp_path):
+    """Whole pipeline incl. tone map and BMP writer: the file must be byte-identical to the reference's."""
+    k = KNOWN[name]
+    over = {a: os.path.join(ROOT, b) for a, b in k["overrides"].items()}
+    out = str(tmp_path / "o.bmp")
+    scene = rt.Scene(os.path.join(ROOT, k["prefix"]), **over)
+    renderer.upload(scene)
+    renderer.frame_begin()
+    g = renderer.render_host()
+    rgba = renderer.tonemap_host(g["rgb"], g["minmax"], scene.gamma)
+    rt.save_bmp24(rgba, out)
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == k["bmp_sha256"]
+
+
+def test_command_line_end_to_end(tmp_path):
+    """The C host (loaders -> rtVisualizedSceneRaytrace -> ToBitmap -> rtBitmapSave) as a user runs it."""
+    k = KNOWN["s3"]
+    out, ids = str(tmp_path / "o.bmp"), str(tmp_path / "ids.bin")
+    exe = os.path.join(ROOT, "raytracer_amd", "raytrace")
+    p = subprocess.run([exe, "-s", os.path.join(ROOT, k["prefix"]), "-o", out, "-I", ids], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert hashlib.sha256(open(ids, "rb").read()).hexdigest() == k["ids_sha256"]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == k["bmp_sha256"]
+
+
+def test_command_line_resolution_override_and_textured_config(tmp_path):
+    exe = os.path.join(ROOT, "raytracer_amd", "raytrace")
+    out = str(tmp_path / "o.bmp")
+    p = subprocess.run([exe, "-s", os.path.join(ROOT, "scenes/pokoj/s2"), "-C", os.path.join(ROOT, "scenes/cegly.cfg"),
+                        "-W", "160", "-H", "120", "-o", out], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    z = np.load(os.path.join(ROOT, "tests/golden/pokoj_cegly.npz"))
+    data = np.frombuffer(open(out, "rb").read()[54:], np.uint8).reshape(120, 160 * 3)[::-1].reshape(120, 160, 3)[:, :, ::-1]
+    # same image as the oracle's (textured, cegly.cfg gamma 2.0) outside the reference's undefined pixels
+    osc = O.OracleScene(os.path.join(ROOT, "scenes/pokoj/s2"), texture=True, width=160, height=120, cfg=os.path.join(ROOT, "scenes/cegly.cfg"))
+    o = osc.render(shadow_cache=False)
+    want = O.rgba_to_u8(O.tonemap(o["rgb"], o["minmax"], osc.gamma)).astype(int)
+    clean = o["taint"] == 0
+    assert np.abs(data.astype(int) - want)[clean].max() <= 1
+    assert np.array_equal(o["ids"], z["ids"])
