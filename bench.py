@@ -171,6 +171,15 @@ def main():
                          "note": "logical bytes (64 B/ray + 8 B/voxel + 40 B/listed triangle); the scene is cache-resident, "
                                  "so frac can exceed 1 without touching HBM; the kernel is fp32-VALU bound"},
         }
+        def ratio(a, b):
+            return round(a / b, 4) if b else None
+        out["walk_stats_rank0"] = {
+            f: {"simd_efficiency": ratio(cnt[f + "_lane_tests"], cnt[f + "_lane_slots"]),
+                "wave_tests": cnt[f + "_lane_slots"] // 64, "wave_cell_visits": cnt[f + "_visits"],
+                "reached_second_slabs": ratio(cnt[f + "_stage2"], cnt[f + "_lane_slots"] / 64),
+                "reached_distance_stage": ratio(cnt[f + "_stage3"], cnt[f + "_lane_slots"] / 64),
+                "reached_exact_test": ratio(cnt[f + "_exact"], cnt[f + "_lane_slots"] / 64)}
+            for f in ("nearest", "shadow")}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(prefix, over, args.cpu_width, args.cpu_height)

@@ -98,6 +98,12 @@ typedef struct rtgpu_counters {
   /* SIMD efficiency of the two walk kernels (only with "count" = 1): triangle tests executed by
    * active lanes / lane slots the wavefronts spent on them (64 per triangle iteration). */
   int64_t nearest_lane_tests, nearest_lane_slots, shadow_lane_tests, shadow_lane_slots;
+  /* How far the staged triangle filter had to go (only with "count" = 1): wavefront-level triangle
+   * iterations in which at least one lane reached the second slab pair, the distance stage, and the
+   * exact Moeller-Trumbore test (src/intersection.c:58-86).  Compare with *_lane_slots / 64. */
+  int64_t nearest_stage2, nearest_stage3, nearest_exact, shadow_stage2, shadow_stage3, shadow_exact;
+  /* Cell visits of the wavefronts: iterations of the walk kernels' outer loop (only with "count" = 1). */
+  int64_t nearest_visits, shadow_visits;
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP

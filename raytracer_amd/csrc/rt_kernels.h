@@ -8,12 +8,6 @@
 #include "rt_math.h"
 #include "rt_texture.h"
 
-#ifndef RT_SOURCE
-#define RT_SOURCE 1  // how a cell's triangle list reaches the lanes: 0 = scalar loads, 1 = LDS-staged batches
-#endif
-#ifndef RT_LDS_PIPELINE
-#define RT_LDS_PIPELINE 0
-#endif
 #ifndef RT_UNROLL
 #define RT_UNROLL 2
 #endif
@@ -27,84 +21,141 @@ RT_D int lane_id() { return threadIdx.x & 63; }
 RT_D unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
 // Streams the packed triangle list [beg, end) of one cell through every lane of the wavefront.
-// f(a, ab, ac, record, index) is called once per record, in list order, with wave-uniform arguments;
-// more() is a wave-uniform predicate evaluated after each record (false = stop early).
-//
-// RT_SOURCE 1: the wavefront copies the list to its private LDS slice in batches of kBatch records with
-// coalesced 16-byte vector loads (64 lanes x 16 B = 21 records per instruction), then every lane reads the
-// same record back (LDS broadcast, two 16-byte reads + one 4-byte read per test; id and kt only on a hit).
-// LDS operations of one wavefront execute in issue order, so no barrier is needed between the copy and
-// the reads, nor before the next batch overwrites the slice.
-// RT_SOURCE 0: wave-uniform global loads (scalar cache path).
-constexpr int kBatch = 64;
-constexpr int kRecFloats = 12;
+// The wavefront copies the list to its private LDS slice in batches of kBatch records with coalesced
+// 16-byte direct-to-LDS loads, then every lane reads the same record back (LDS broadcast).  batch(k1, k2) is
+// called once per batch with the batch's filter constants, f(record, index) once per record, in list
+// order, with wave-uniform arguments; more() is a wave-uniform predicate evaluated after each record
+// (false = stop early).  LDS operations of one wavefront execute in issue order, so no barrier is needed
+// between the copy and the reads, nor before the next batch overwrites the slice.
 using v4f = float __attribute__((ext_vector_type(4)));
+using v2f = float __attribute__((ext_vector_type(2)));
+constexpr int kRecVecs = kRecFloats / 4;
+constexpr int kStageLoads = (kBatch * kRecVecs + 63) / 64;
 
-template <typename F, typename G>
-RT_D void stream_cell(const TriRec *__restrict__ recs, uint32_t beg, uint32_t end, float *slice, int lane, F &&f, G &&more) {
-#if RT_SOURCE == 1
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4): the LDS address is
+// the wave-uniform `lds_base` plus 16 x lane.
+RT_D void glds16(const float4 *src, float *lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+
+// True if the predicate holds in any active lane.  The result goes through an opaque scalar register so
+// that the branch on it stays a scalar branch (otherwise it is merged into the per-lane predicate and
+// the common path pays for the exec-mask bookkeeping of the rare one).
+RT_D bool wave_any(bool p) {
+  unsigned long long m = __ballot(p);
+  asm volatile("" : "+s"(m));
+  return m != 0;
+}
+
+// pass1(record) is the side-effect-free first stage of the test (true = this lane cannot reject the
+// triangle yet); it is evaluated for RT_UNROLL records at a time, and only if it holds in some lane for
+// some of them does the wavefront leave the straight-line path and run the full test f(record, index)
+// on those records, in list order, checking more() after each.
+template <typename B, typename P, typename F, typename G>
+RT_D void stream_cell(const TriRec *__restrict__ recs, uint32_t beg, uint32_t end, float *slice, int lane, B &&batch,
+                      P &&pass1, F &&f, G &&more) {
   for (uint32_t c0 = beg; c0 < end; c0 += kBatch) {
     const int n = (int)(end - c0 < (uint32_t)kBatch ? end - c0 : (uint32_t)kBatch);
-    const int nvec = n * 3;
+    const int nvec = n * kRecVecs;
     const float4 *src = reinterpret_cast<const float4 *>(recs + c0);
-    float4 *dst = reinterpret_cast<float4 *>(slice);
-    float4 v0, v1, v2;
-    if (lane < nvec) v0 = src[lane];
-    if (lane + 64 < nvec) v1 = src[lane + 64];
-    if (lane + 128 < nvec) v2 = src[lane + 128];
-    if (lane < nvec) dst[lane] = v0;
-    if (lane + 64 < nvec) dst[lane + 64] = v1;
-    if (lane + 128 < nvec) dst[lane + 128] = v2;
+    // global -> LDS without passing through registers: lane L's 16 bytes land at base + 16 L
+    static_assert(kStageLoads <= 5, "staging is written out for up to five loads per lane");
+    if (lane < nvec) glds16(src + lane, slice);
+    if (kStageLoads > 1 && lane + 64 < nvec) glds16(src + lane + 64, slice + 256);
+    if (kStageLoads > 2 && lane + 128 < nvec) glds16(src + lane + 128, slice + 512);
+    if (kStageLoads > 3 && lane + 192 < nvec) glds16(src + lane + 192, slice + 768);
+    if (kStageLoads > 4 && lane + 256 < nvec) glds16(src + lane + 256, slice + 1024);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    // all nine floats of a record feed the branch-free part of the test, so the three reads
-    // (16 + 16 + 4 bytes, same address in every lane = LDS broadcast) sit together at the top
-#if RT_LDS_PIPELINE
-    v4f x = *reinterpret_cast<const v4f *>(slice);
-    v4f y = *reinterpret_cast<const v4f *>(slice + 4);
-    float z = slice[8];
-    for (int j = 0; j < n; ++j) {
-      const float *R = slice + j * kRecFloats;
-      const float *N = slice + (j + 1 < kBatch ? j + 1 : j) * kRecFloats;  // next record, read one test ahead
-      const v4f nx = *reinterpret_cast<const v4f *>(N);
-      const v4f ny = *reinterpret_cast<const v4f *>(N + 4);
-      const float nz = N[8];
-      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R, c0 + (uint32_t)j);
-      if (!more()) return;
-      x = nx; y = ny; z = nz;
+    batch(slice[10], slice[11]);
+    int j = 0;
+    for (; j + RT_UNROLL <= n; j += RT_UNROLL) {
+      unsigned long long m[RT_UNROLL], any = 0;
+#pragma unroll
+      for (int q = 0; q < RT_UNROLL; q++) { m[q] = __ballot(pass1(slice + (j + q) * kRecFloats)); any |= m[q]; }
+      asm volatile("" : "+s"(any));
+      if (any != 0) {
+        asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into per-lane ones
+#pragma unroll
+        for (int q = 0; q < RT_UNROLL; q++) {
+          if (m[q] != 0) {
+            f(slice + (j + q) * kRecFloats, c0 + (uint32_t)(j + q));
+            if (!more()) return;
+          }
+        }
+      }
     }
-#else
-#pragma unroll RT_UNROLL
-    for (int j = 0; j < n; ++j) {
-      const float *R = slice + j * kRecFloats;
-      const v4f x = *reinterpret_cast<const v4f *>(R);
-      const v4f y = *reinterpret_cast<const v4f *>(R + 4);
-      const float z = R[8];
-      f(mk3(x.x, x.y, x.z), mk3(x.w, y.x, y.y), mk3(y.z, y.w, z), R, c0 + (uint32_t)j);
-      if (!more()) return;
+    for (; j < n; ++j) {
+      if (wave_any(pass1(slice + j * kRecFloats))) {
+        asm volatile("; some lane passed the first slab");
+        f(slice + j * kRecFloats, c0 + (uint32_t)j);
+        if (!more()) return;
+      }
     }
-#endif
     __builtin_amdgcn_wave_barrier();
   }
-#else
-  for (uint32_t t = beg; t < end; ++t) {
-    const TriRec *T = recs + t;
-    f(ld3(T->a), ld3(T->ab), ld3(T->ac), reinterpret_cast<const float *>(T), t);
-    if (!more()) return;
-  }
-#endif
 }
-// id and kt of the record handed to f (read only when a test succeeds)
-RT_D int rec_id(const float *R) { return __float_as_int(R[9]); }
-RT_D float rec_kt(const float *R) { return R[10]; }
-
-// One lane's own record fetch (per-lane and one-ray-per-wave modes): 16 + 16 + 4 bytes from L1/L2.
-RT_D const float *load_rec(const TriRec *__restrict__ recs, uint32_t idx, f3 &a, f3 &ab, f3 &ac) {
-  const float *R = reinterpret_cast<const float *>(recs + idx);
+// Field access of a record in LDS or in memory (float index: n 0-2, ik 3-5, q 6-8, id 9, k1 10, k2 11,
+// ij 12-14, p 15-17, an 18, kt 19).  The first slab needs floats 0-8: two 16-byte reads and one 4-byte read.
+struct RecA { f3 n, ac, q; };
+struct RecB { f3 ab, p; float an, kt; };
+RT_D RecA rec_a(const float *R) {
   const v4f x = *reinterpret_cast<const v4f *>(R);
   const v4f y = *reinterpret_cast<const v4f *>(R + 4);
   const float z = R[8];
-  a = mk3(x.x, x.y, x.z); ab = mk3(x.w, y.x, y.y); ac = mk3(y.z, y.w, z);
-  return R;
+  RecA a; a.n = mk3(x.x, x.y, x.z); a.ac = mk3(x.w, y.x, y.y); a.q = mk3(y.z, y.w, z);
+  return a;
+}
+RT_D RecB rec_b(const float *R) {
+  const v4f x = *reinterpret_cast<const v4f *>(R + 12);
+  const v4f y = *reinterpret_cast<const v4f *>(R + 16);
+  RecB b; b.ab = mk3(x.x, x.y, x.z); b.p = mk3(x.w, y.x, y.y); b.an = y.z; b.kt = y.w;
+  return b;
+}
+RT_D int rec_id(const float *R) { return __float_as_int(R[9]); }
+// The exact test of a triangle the filter could not decide: i, ij, ik by index.
+RT_D bool exact_test(const GridP &g, int id, f3 o, f3 r, float &d, float &u, float &v) {
+  const float *G = g.geom + 9 * (long long)id;
+  return tri_test(ld3(G), ld3(G + 3), ld3(G + 6), o, r, d, u, v);
+}
+
+// What one nearest-hit test concludes from the later stages, for a lane that passed the first slab.
+// true: tri_test has to be run; false: whatever tri_test answers, the triangle cannot replace the current
+// best (rejected, behind the origin, or surely not nearer than `best`).
+RT_D bool nearest_needs_exact(const float *R, const RecA &A, PlTest &t, f3 o, f3 r, f3 m, float kc, float lmax, float best,
+                              bool &s3) {
+  s3 = false;
+  const RecB B = rec_b(R);
+  if (!pl_stage2(B.ab, B.p, r, m, t)) return false;
+  s3 = true;
+  const float sd = pl_sdist(A.n, B.an, o, t), e = lmax * kc, ad = __builtin_fabsf(t.det);
+  const bool sure = pl_sign_sure(t, kc);
+  const bool behind = sd + e < 0.0f;
+  const bool farther = (sd - e > 0.0f) & (sd - e > best * (ad + kc) * 1.00001f);
+  return !(sure & (behind | farther));
+}
+// The same for a shadow test.  Returns 0 = no effect on the shadow ray, 1 = tri_test has to be run,
+// 2 = surely an accepted hit of a transparent triangle (ts *= kt), 3 = surely an opaque blocker in (1e-5, dmax).
+RT_D int shadow_verdict(const float *R, const RecA &A, PlTest &t, f3 o, f3 r, f3 m, float kc, float lmax, float dmax,
+                        float &kt, bool &s3) {
+  s3 = false;
+  const RecB B = rec_b(R);
+  if (!pl_stage2(B.ab, B.p, r, m, t)) return 0;
+  s3 = true;
+  kt = B.kt;
+  const float sd = pl_sdist(A.n, B.an, o, t), e = lmax * kc, ad = __builtin_fabsf(t.det);
+  const bool sure = pl_sign_sure(t, kc), inside = pl_surely_inside(t, kc);
+  if (kt > 0.0f) {
+    if (sure & (sd + e < 0.0f)) return 0;             // d < 0: rejected
+    if (inside & (sd - e > 0.0f)) return 2;
+    return 1;
+  }
+  const bool out = (sd + e < 0.0000099f * (ad - kc)) | (sd - e > dmax * (ad + kc) * 1.00001f);
+  if (sure & out) return 0;                           // wherever it is hit, not inside (1e-5, dmax)
+  const bool in = (sd - e > 0.0000101f * (ad + kc)) & (sd + e < dmax * (ad - kc) * 0.99999f);
+  if (inside & in) return 3;
+  return 1;
 }
 RT_D float lane_bcast(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 RT_D f3 lane_bcast3(f3 v, int l) { return mk3(lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)); }
@@ -137,8 +188,11 @@ RT_D int pick_mode(int group, uint32_t leader_cnt, int short_lanes) {
 // ------------------------------------------------------------------------------------------------
 // Per-triangle preprocess for one camera (preprocess.c:17-32): ij, ik, unit normal flipped towards
 // the observer, plane offset d.  geom: 9 floats (i, ij, ik); aux: 4 floats (n, d).
-__global__ void k_preprocess(int nt, const float *__restrict__ verts, f3 ob, float *__restrict__ geom,
-                             float *__restrict__ aux) {
+// Also the per-triangle record of the staged filter (rt_math.h), evaluated in double from the float edges
+// and rounded once, with the triangle's own error constants k1, k2, and the surface's kt.
+__global__ void k_preprocess(int nt, const float *__restrict__ verts, f3 ob, const int32_t *__restrict__ sid,
+                             const SurfaceD *__restrict__ surf, float *__restrict__ geom, float *__restrict__ aux,
+                             float *__restrict__ filt) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nt) return;
   f3 a = ld3(verts + 9 * t), b = ld3(verts + 9 * t + 3), c = ld3(verts + 9 * t + 6);
@@ -149,6 +203,39 @@ __global__ void k_preprocess(int nt, const float *__restrict__ verts, f3 ob, flo
   float d = -dot3(a, n);
   st3(geom + 9 * t, a); st3(geom + 9 * t + 3, ab); st3(geom + 9 * t + 6, ac);
   st3(aux + 4 * t, n); aux[4 * t + 3] = d;
+  // The filter's constants, in double from the float i, ij, ik the reference computes with.  Vertices
+  // A = i, B = i + ij, C = i + ik; relabelled (a', b', c') so that c' - a' is the longest edge.
+  const double A[3] = {a.x, a.y, a.z}, AB[3] = {ab.x, ab.y, ab.z}, AC[3] = {ac.x, ac.y, ac.z};
+  double B[3], C[3], BC[3];
+  for (int k = 0; k < 3; k++) { B[k] = A[k] + AB[k]; C[k] = A[k] + AC[k]; BC[k] = AC[k] - AB[k]; }
+  auto len = [](const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+  const double lab = len(AB), lac = len(AC), lbc = len(BC);
+  double a2[3], ab2[3], ac2[3];
+  if (lac >= lab && lac >= lbc) {
+    for (int k = 0; k < 3; k++) { a2[k] = A[k]; ab2[k] = AB[k]; ac2[k] = AC[k]; }
+  } else if (lab >= lbc) {
+    for (int k = 0; k < 3; k++) { a2[k] = A[k]; ab2[k] = AC[k]; ac2[k] = AB[k]; }
+  } else {
+    for (int k = 0; k < 3; k++) { a2[k] = B[k]; ab2[k] = -AB[k]; ac2[k] = BC[k]; }
+  }
+  auto cross = [](const double *x, const double *y, double *z) {
+    z[0] = x[1] * y[2] - x[2] * y[1]; z[1] = x[2] * y[0] - x[0] * y[2]; z[2] = x[0] * y[1] - x[1] * y[0];
+  };
+  double N[3], Q[3], P[3];
+  cross(ac2, ab2, N); cross(ac2, a2, Q); cross(a2, ab2, P);
+  const double L = fmax(lab, fmax(lac, lbc)), amax = fmax(len(A), fmax(len(B), len(C)));
+  const double eps = 5.9604644775390625e-8;  // 2^-24
+  float *F = filt + kRecFloats * t;
+  F[0] = (float)N[0]; F[1] = (float)N[1]; F[2] = (float)N[2];
+  F[3] = (float)ac2[0]; F[4] = (float)ac2[1]; F[5] = (float)ac2[2];
+  F[6] = (float)Q[0]; F[7] = (float)Q[1]; F[8] = (float)Q[2];
+  F[9] = __int_as_float(t);
+  F[10] = (float)(144.0 * eps * L * 1.001);
+  F[11] = (float)((144.0 * eps * L * amax + 56.0 * eps * L * L) * 1.001 + 1e-30);
+  F[12] = (float)ab2[0]; F[13] = (float)ab2[1]; F[14] = (float)ab2[2];
+  F[15] = (float)P[0]; F[16] = (float)P[1]; F[17] = (float)P[2];
+  F[18] = (float)(a2[0] * N[0] + a2[1] * N[1] + a2[2] * N[2]);
+  F[19] = surf[sid[t]].kt;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -205,9 +292,7 @@ __global__ void __launch_bounds__(1024) k_scan_cells(int n, const uint32_t *__re
 // Grid build, pass 2: one wavefront per cell walks the triangles in index order, 64 at a time, and
 // appends those whose voxel box contains the cell; ballot + prefix count keeps the list in ascending
 // triangle order, which is the reference's insertion order and therefore its tie-break.
-__global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *__restrict__ box,
-                                                   const float *__restrict__ geom, const int32_t *__restrict__ sid,
-                                                   const SurfaceD *__restrict__ surf, TriRec *__restrict__ recs,
+__global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *__restrict__ box, TriRec *__restrict__ recs,
                                                    int32_t *__restrict__ refs) {
   int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cell >= g.ncells) return;
@@ -226,16 +311,33 @@ __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *_
     unsigned long long m = __ballot(in);
     if (in) {
       uint32_t p = pos + __popcll(m & lanes_below(lane));
-      TriRec r;
+      const float4 *F = reinterpret_cast<const float4 *>(g.filt + kRecFloats * (long long)t);
+      float4 *R = reinterpret_cast<float4 *>(recs + p);
 #pragma unroll
-      for (int q = 0; q < 3; q++) { r.a[q] = geom[9 * t + q]; r.ab[q] = geom[9 * t + 3 + q]; r.ac[q] = geom[9 * t + 6 + q]; }
-      r.id = t;
-      r.kt = surf[sid[t]].kt;
-      r.pad = 0;
-      recs[p] = r;
+      for (int q = 0; q < kRecVecs; q++) R[q] = F[q];
       refs[p] = t;
     }
     pos += __popcll(m);
+  }
+}
+// Grid build, pass 3: the filter's error constants k1, k2 of every record are replaced by their maxima
+// over the record's batch (positions 64b .. 64b+63 of the cell's list), so that the cell-mode walk
+// needs one pair per batch.  One wavefront per cell.
+__global__ void __launch_bounds__(256) k_grid_kmax(GridP g, TriRec *__restrict__ recs) {
+  int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= g.ncells) return;
+  const uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
+  const int lane = lane_id();
+  for (uint32_t c0 = beg; c0 < end; c0 += kBatch) {
+    const uint32_t p = c0 + lane;
+    float k1 = 0.0f, k2 = 0.0f;
+    if (p < end) { k1 = recs[p].k1; k2 = recs[p].k2; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      k1 = fmaxf(k1, __shfl_xor(k1, off));
+      k2 = fmaxf(k2, __shfl_xor(k2, off));
+    }
+    if (p < end) { recs[p].k1 = k1; recs[p].k2 = k2; }
   }
 }
 
@@ -290,7 +392,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
   const int nrays = ctl->count[level];
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
-  unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0;
+  unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0;
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
   for (;;) {
     uint32_t base = 0;
@@ -305,6 +407,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     nPixels += __popcll(__ballot(ry.i != -2));
     nTraced += __popcll(__ballot(alive));
     const f3 o = ld3(ry.o), r = ld3(ry.r);
+    f3 pm = mk3(0.0f, 0.0f, 0.0f);  // o x r and |o|: the ray's side of the rejection filter
+    float onorm = 0.0f;
+    if (alive) pl_ray(o, r, pm, onorm);
     Hit h;
     h.tri = alive ? -1 : -2;
     h.d = h.u = h.v = 0.0f; h.i = h.j = h.k = 0; h.pad = 0;
@@ -333,26 +438,45 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       const bool in_group = alive && mycell == cell;
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
+      if (COUNT) nVisit++;
       // exit distance of this voxel: a hit only counts if it lies before it (voxelize.c:569,574)
       float best = min3_ref(w.tx + w.dtx, w.ty + w.dty, w.tz + w.dtz);
       int best_id = -1;
       float best_u = 0.0f, best_v = 0.0f;
       bool proc;  // this lane's current cell is fully tested after this step
+      // One triangle for one ray: the filter, then tri_test for what it cannot decide.  Everything after the
+      // first slab sits behind one scalar branch that is taken only if some lane of the wavefront passed it.
+      auto test = [&](const float *R, f3 to, f3 tr, f3 tm, float kc, int cur, float &b, int &bid, float &bu, float &bv,
+                      uint32_t pos, uint32_t &bpos) {
+        const RecA A = rec_a(R);
+        PlTest t;
+        const bool p1 = pl_stage1(A.n, A.ac, A.q, tr, tm, kc, t);
+        if (wave_any(p1)) {
+          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into the per-lane one
+          bool s3 = false, ex = false;
+          if (p1) ex = nearest_needs_exact(R, A, t, to, tr, tm, kc, g.lmax, b, s3);
+          if (COUNT) { nS2++; nS3 += __ballot(s3) != 0; nEx += __ballot(ex) != 0; }
+          if (ex) {
+            const int id = rec_id(R);
+            float d, u, v;
+            if (exact_test(g, id, to, tr, d, u, v) && id != cur && d < b) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
+          }
+        }
+      };
+      uint32_t nopos = 0;
       if (mode == kCellMode) {
         proc = in_group;
         if (COUNT) { nWave += (unsigned long long)cnt; if (proc) nLane += cnt; }
-        const f3 rr = proc ? r : mk3(0.0f, 0.0f, 0.0f);  // lanes outside the cell test with r = 0: never a candidate
+        // lanes outside the cell test with kc = -inf: rejected by the first slab
+        float kc = -INFINITY;
         stream_cell(recs, beg, beg + cnt, slice, lane,
-                    [&](f3 ta, f3 tab, f3 tac, const float *R, uint32_t) {
-                      float det, tp; f3 tv;
-                      if (tri_candidate(ta, tab, tac, o, rr, det, tp, tv)) {
-                        float d, u, v;
-                        if (tri_exact(tab, tac, r, det, tp, tv, d, u, v)) {
-                          const int id = rec_id(R);
-                          if (id != ry.current && d < best) { best = d; best_id = id; best_u = u; best_v = v; }
-                        }
-                      }
+                    [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) : -INFINITY; },
+                    [&](const float *R) {
+                      const RecA A = rec_a(R);
+                      PlTest t;
+                      return pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
                     },
+                    [&](const float *R, uint32_t) { test(R, o, r, pm, kc, ry.current, best, best_id, best_u, best_v, 0u, nopos); },
                     [] { return true; });
       } else if (mode == kLaneMode) {
         proc = is_short;
@@ -360,21 +484,15 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
           if (i < pn) {
-            f3 ta, tab, tac; float det, tp; f3 tv;
-            const float *R = load_rec(recs, mybeg + i, ta, tab, tac);
-            if (tri_candidate(ta, tab, tac, o, r, det, tp, tv)) {
-              float d, u, v;
-              if (tri_exact(tab, tac, r, det, tp, tv, d, u, v)) {
-                const int id = rec_id(R);
-                if (id != ry.current && d < best) { best = d; best_id = id; best_u = u; best_v = v; }
-              }
-            }
+            const float *R = reinterpret_cast<const float *>(recs + mybeg + i);
+            test(R, o, r, pm, __builtin_fmaf(R[10], onorm, R[11]), ry.current, best, best_id, best_u, best_v, 0u, nopos);
           }
         }
       } else {
         // ray mode: the leader's ray against 64 triangles per step; lane L takes list positions L, L+64, ...
         proc = lane == leader;
-        const f3 lo = lane_bcast3(o, leader), lr = lane_bcast3(r, leader);
+        const f3 lo = lane_bcast3(o, leader), lr = lane_bcast3(r, leader), lm = lane_bcast3(pm, leader);
+        const float lon = lane_bcast(onorm, leader);
         const int lcur = __builtin_amdgcn_readlane(ry.current, leader);
         float cb = lane_bcast(best, leader), cu = 0.0f, cv = 0.0f;
         int cid = -1;
@@ -383,15 +501,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
           if (t < beg + cnt) {
-            f3 ta, tab, tac; float det, tp; f3 tv;
-            const float *R = load_rec(recs, t, ta, tab, tac);
-            if (tri_candidate(ta, tab, tac, lo, lr, det, tp, tv)) {
-              float d, u, v;
-              if (tri_exact(tab, tac, lr, det, tp, tv, d, u, v)) {
-                const int id = rec_id(R);
-                if (id != lcur && d < cb) { cb = d; cpos = t; cid = id; cu = u; cv = v; }  // ascending t: earliest wins in a lane
-              }
-            }
+            const float *R = reinterpret_cast<const float *>(recs + t);
+            test(R, lo, lr, lm, __builtin_fmaf(R[10], lon, R[11]), lcur, cb, cid, cu, cv, t, cpos);  // ascending t: earliest wins in a lane
           }
         }
         // smallest d, ties to the earliest list position: the reference's strict `d < dmin` scan order
@@ -439,6 +550,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       atomicAdd(&ctl->stat[kNearS], nS); atomicAdd(&ctl->stat[kNearT], nT);
       atomicAdd(&ctl->stat[kNearLaneTests], nLane); atomicAdd(&ctl->stat[kNearWaveTests], nWave * 64ull);
       atomicAdd(&ctl->stat[kNearestQ], nQ);
+      atomicAdd(&ctl->stat[kNearStage2], nS2); atomicAdd(&ctl->stat[kNearStage3], nS3); atomicAdd(&ctl->stat[kNearExact], nEx);
+      atomicAdd(&ctl->stat[kNearVisits], nVisit);
     }
   }
 }
@@ -583,7 +696,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   const long long total = (long long)n * sp.nslots;
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
-  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0;
+  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0;
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&ctl->ticket_shadow[level], 64u);
@@ -592,8 +705,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     const long long item = (long long)base + lane;
     bool alive = false;
     int slot = 0, nidx = 0, current = -1;
-    f3 a = mk3(0, 0, 0), r = mk3(0, 0, 0);
-    float dmax = 0.0f, ts = 1.0f, result = 1.0f;
+    f3 a = mk3(0, 0, 0), r = mk3(0, 0, 0), pm = mk3(0, 0, 0);  // pm = a x r, onorm >= |a|: the filter's ray side
+    float dmax = 0.0f, ts = 1.0f, result = 1.0f, onorm = 0.0f;
     bool have_result = false;
     Dda w;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -622,6 +735,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
 #pragma unroll
             for (int c = 0; c < 3; c++) { lo[c] = ai[c] < bi[c] ? ai[c] : bi[c]; hi[c] = ai[c] < bi[c] ? bi[c] : ai[c]; }
             dda_init(g, a, r, ai[0], ai[1], ai[2], w);
+            pl_ray(a, r, pm, onorm);
             alive = true;
             if (COUNT) nW++;
             for (;;) {
@@ -645,57 +759,78 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       const bool in_group = alive && mycell == cell;
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
+      if (COUNT) nVisit++;
       bool proc;  // this lane's current cell is fully tested (or the ray blocked) after this step
-      if (mode == kCellMode) {
-        proc = in_group;
-        bool in = in_group;
-        f3 rr = in ? r : mk3(0.0f, 0.0f, 0.0f);  // lanes outside the cell, and blocked ones, test with r = 0
-        auto test = [&](f3 ta, f3 tab, f3 tac, const float *R, uint32_t) {
-          float det, tp; f3 tv;
-          if (tri_candidate(ta, tab, tac, a, rr, det, tp, tv)) {
-            float d, u, v;
-            if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
-              const float kt = rec_kt(R);
-              if (kt > 0.0f) {
-                ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
-              } else if (d > 0.00001f && d < dmax) {
-                result = -1.0f; alive = false; in = false; rr = mk3(0.0f, 0.0f, 0.0f);  // opaque blocker (:707-711)
-              }
+      // One triangle for one shadow ray: 0 = no effect, 2 = accepted hit of a transparent triangle, 3 = opaque
+      // blocker inside (1e-5, dmax); the filter decides what it can prove, tri_test the rest (:700-711).
+      // react(verdict, kt) runs, with all lanes of the caller active, only when some lane passed the first slab.
+      auto test = [&](const float *R, f3 to, f3 tr, f3 tm, float kc, int cur, float tdmax, auto &&react) {
+        const RecA A = rec_a(R);
+        PlTest t;
+        const bool p1 = pl_stage1(A.n, A.ac, A.q, tr, tm, kc, t);
+        if (wave_any(p1)) {
+          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into the per-lane one
+          bool s3 = false;
+          int verdict = 0;
+          float kt = 0.0f;
+          if (p1) verdict = shadow_verdict(R, A, t, to, tr, tm, kc, g.lmax, tdmax, kt, s3);
+          if (COUNT) { nS2++; nS3 += __ballot(s3) != 0; nEx += __ballot(verdict == 1) != 0; }
+          if (verdict != 0) {
+            const int id = rec_id(R);
+            if (id == cur) {
+              verdict = 0;
+            } else if (verdict == 1) {
+              float d, u, v;
+              verdict = !exact_test(g, id, to, tr, d, u, v) ? 0 : kt > 0.0f ? 2 : (d > 0.00001f && d < tdmax) ? 3 : 0;
             }
           }
-        };
-        if (__ballot(in) != 0)
+          react(verdict, kt);
+        }
+      };
+      if (mode == kCellMode) {
+        proc = in_group;
+        // lanes outside the cell, and blocked ones, test with kc = -inf: rejected by the first slab
+        float kc = -INFINITY;
+        bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
+        if (go)
           stream_cell(recs, beg, beg + cnt, slice, lane,
-                      [&](f3 ta, f3 tab, f3 tac, const float *R, uint32_t pos) {
-                        if (COUNT) { nWave++; if (in) nLane++; }
-                        test(ta, tab, tac, R, pos);
+                      [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) : -INFINITY; },
+                      [&](const float *R) {
+                        if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
+                        const RecA A = rec_a(R);
+                        PlTest t;
+                        return pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
                       },
-                      [&] { return __ballot(in) != 0; });
+                      [&](const float *R, uint32_t) {
+                        test(R, a, r, pm, kc, current, dmax, [&](int verdict, float kt) {
+                          if (verdict == 2) {
+                            ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
+                          } else if (verdict == 3) {
+                            result = -1.0f; kc = -INFINITY;
+                          }
+                          go = __ballot(kc != -INFINITY) != 0;
+                        });
+                      },
+                      [&] { return go; });
+        alive = alive & (result >= 0.0f);
       } else if (mode == kLaneMode) {
         proc = is_short;
         uint32_t pn = proc ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
           if (i < pn) {
-            f3 ta, tab, tac; float det, tp; f3 tv;
-            const float *R = load_rec(recs, mybeg + i, ta, tab, tac);
-            if (tri_candidate(ta, tab, tac, a, r, det, tp, tv)) {
-              float d, u, v;
-              if (tri_exact(tab, tac, r, det, tp, tv, d, u, v) && rec_id(R) != current) {
-                const float kt = rec_kt(R);
-                if (kt > 0.0f) {
-                  ts *= kt;
-                } else if (d > 0.00001f && d < dmax) {
-                  result = -1.0f; alive = false; pn = 0u;
-                }
-              }
-            }
+            const float *R = reinterpret_cast<const float *>(recs + mybeg + i);
+            test(R, a, r, pm, __builtin_fmaf(R[10], onorm, R[11]), current, dmax, [&](int verdict, float kt) {
+              if (verdict == 2) ts *= kt;
+              else if (verdict == 3) { result = -1.0f; alive = false; pn = 0u; }
+            });
           }
         }
       } else {
         // ray mode: the leader's shadow ray against 64 triangles per step
         proc = lane == leader;
-        const f3 la = lane_bcast3(a, leader), lr = lane_bcast3(r, leader);
+        const f3 la = lane_bcast3(a, leader), lr = lane_bcast3(r, leader), lm = lane_bcast3(pm, leader);
+        const float lon = lane_bcast(onorm, leader);
         const int lcur = __builtin_amdgcn_readlane(current, leader);
         const float ldmax = lane_bcast(dmax, leader);
         float cts = lane_bcast(ts, leader);
@@ -703,23 +838,15 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         for (uint32_t t0 = beg; t0 < beg + cnt && !blocked; t0 += 64) {
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
-          bool transparent = false, opaque = false;
+          int verdict = 0;
           float kt = 0.0f;
           if (t < beg + cnt) {
-            f3 ta, tab, tac; float det, tp; f3 tv;
-            const float *R = load_rec(recs, t, ta, tab, tac);
-            if (tri_candidate(ta, tab, tac, la, lr, det, tp, tv)) {
-              float d, u, v;
-              if (tri_exact(tab, tac, lr, det, tp, tv, d, u, v) && rec_id(R) != lcur) {
-                kt = rec_kt(R);
-                if (kt > 0.0f) transparent = true;
-                else if (d > 0.00001f && d < ldmax) opaque = true;
-              }
-            }
+            const float *R = reinterpret_cast<const float *>(recs + t);
+            test(R, la, lr, lm, __builtin_fmaf(R[10], lon, R[11]), lcur, ldmax, [&](int vd, float k) { verdict = vd; kt = k; });
           }
           // the transparency product is taken in list order, like the reference's scan
-          for (unsigned long long tm = __ballot(transparent); tm != 0; tm &= tm - 1) cts *= lane_bcast(kt, __ffsll(tm) - 1);
-          blocked = __ballot(opaque) != 0;
+          for (unsigned long long tm = __ballot(verdict == 2); tm != 0; tm &= tm - 1) cts *= lane_bcast(kt, __ffsll(tm) - 1);
+          blocked = __ballot(verdict == 3) != 0;
         }
         if (proc) {
           if (blocked) { result = -1.0f; alive = false; } else ts = cts;
@@ -747,6 +874,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       atomicAdd(&ctl->stat[kShadLaneTests], nLane); atomicAdd(&ctl->stat[kShadWaveTests], nWave * 64ull);
       atomicAdd(&ctl->stat[kShadS], nS); atomicAdd(&ctl->stat[kShadT], nT);
       atomicAdd(&ctl->stat[kShadowQ], nQ); atomicAdd(&ctl->stat[kShadowWalks], nW);
+      atomicAdd(&ctl->stat[kShadStage2], nS2); atomicAdd(&ctl->stat[kShadStage3], nS3); atomicAdd(&ctl->stat[kShadExact], nEx);
+      atomicAdd(&ctl->stat[kShadVisits], nVisit);
     }
   }
 }

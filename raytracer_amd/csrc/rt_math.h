@@ -164,36 +164,76 @@ RT_D bool tri_test(f3 a, f3 ab, f3 ac, f3 o, f3 r, float &d, float &u, float &v)
   return true;
 }
 
-// The same predicate and the same d, u, v as tri_test, split for the GPU into a branch-free common part
-// and a rare exact part.
+// ------------------------------------------------------------------------------------------------
+// Staged conservative filter in front of tri_test.  It never decides differently from tri_test: a stage
+// either proves what tri_test would answer or hands the triangle on; what no stage can prove goes to
+// tri_test itself.  All stages are branch-free FMA chains on per-triangle constants (k_preprocess) and the
+// ray's Pluecker coordinates (r, m = o x r).
 //
-// tri_candidate: p, det, tv and tp = tv.p exactly as intersection.c:62-70 computes them, then a conservative
-// range check of u = tp/det that needs no division:  u in [0,1]  <=>  |2 tp - det| <= |det|.
-// With w = |fma(2, tp, -det)| (one rounding) the triangle is rejected when w >= 1.00002 |det|, i.e. when the
-// real quotient tp/det is outside [-9.9e-6, 1.0000099]; the reference's u = fl(tp * fl(1/det)) is within
-// 3e-7 relative of that quotient, so it is then outside [0,1] as well (and nowhere near the underflow that
-// would turn a tiny negative u into -0).  det = 0 is rejected too (w >= 0), as the reference's |det| < 1e-6
-// test would; a tiny non-zero det with u in range survives and meets that test in tri_exact.  Most
-// triangles of a cell are nowhere near the ray and end here, without the correctly rounded division and
-// without a branch.  A NaN (NaN ray direction after total internal reflection) is never rejected here, as
-// in the reference.  A lane that must not take part passes r = 0: det = tp = 0, rejected.
-RT_D bool tri_candidate(f3 a, f3 ab, f3 ac, f3 o, f3 r, float &det, float &tp, f3 &tv) {
-  f3 p = cross3(r, ac);
-  det = dot3(ab, p);
-  tv = sub3(o, a);
-  tp = dot3(tv, p);
-  const float w = __builtin_fabsf(__builtin_fmaf(2.0f, tp, -det));
-  return !(w >= __builtin_fabsf(det) * 1.00002f);
+// Geometry.  With det = ij.(r x ik), tp = (o-i).(r x ik), vp = r.((o-i) x ij), dp = ik.((o-i) x ij), tri_test
+// accepts iff |det| >= 1e-6, u = tp/det in [0,1], v = vp/det >= 0, u+v <= 1, d = dp/det >= 0.  By the cyclic
+// identity of the triple product
+//     det = r.N            N = ik x ij
+//     tp  = m.ik - r.Q     Q = ik x i
+//     vp  = -(m.ij + r.P)  P = i x ij
+//     dp  = i.N - o.N
+// and (u, v, 1-u-v) all lie in [0,1] exactly when the ray pierces the triangle, whichever vertex is taken
+// as i: the filter may label the vertices as it likes.  k_preprocess labels them so that ik is the longest
+// edge, which makes the first slab, u in [0,1], the narrowest of the three.
+//     x in [0,1]  <=>  |2 x det - det| <= |det|      (no division, no sign case)
+//
+// Rounding.  eps = 2^-24, L = longest edge, A = largest vertex norm, |r| <= 1+1e-6, x* = exact value on
+// the float inputs.  tri_test's route (no FMA):   |det-det*| <= 8.9 eps L^2,  |tp-tp*|, |vp-vp*| <= 10.5 eps L (|o|+A),
+// |dp-dp*| <= 10.5 eps L^2 (|o|+A).  This route (inputs rounded once from double, FMA chains):
+// |det'-det*| <= 4.1 eps L^2, |tp'-tp*|, |vp'-vp*| <= 7.2 eps L (|o|+A), |dp'-dp*| <= 5.1 eps L^2 (|o|+A).
+// (Standard dot-product bounds gamma_n sum|x_i y_i| with sum|x_i y_i| <= |x||y|.)  If tri_test accepts then
+// for X in {tp, vp, det-tp-vp}:  |2X'-det'| <= |det'| (1 + 7 eps) + 71 eps L (|o|+A) + 28 eps L^2.
+// k_preprocess stores k1 = 144 eps L, k2 = 144 eps L A + 56 eps L^2 (twice the bound); kc = k1 |o|' + k2.
+//   reject         some |2X'-det'| > 1.00001 |det'| + kc          => tri_test rejects
+//   surely inside  all  |2X'-det'| <= 0.99999 |det'| - kc, |det'| - kc > 1.01e-6
+//                                                                 => tri_test's det, u, v tests pass
+//   distance       d = dp/det against a bound c with E = lmax kc >= 9 x (|dp'-dp| bound) and |det'-det| <= kc/4:
+//                  s dp' - E > c (|det'| + kc) => d > c,   s dp' + E < c (|det'| - kc) => d < c,  s = sign det'
+// Anything a NaN touches compares false everywhere and ends in tri_test, like every uncertain case.
+// A lane that must not take part passes kc = -inf: anything but a NaN is > -inf, rejected by the first slab
+// (a NaN ray is never blocked and never finds a hit nearer than a number, so it has nothing to lose there).
+struct PlTest {
+  float det, tp, x1, x2, x3, T;
+};
+// first slab: 12 instructions
+RT_D bool pl_stage1(f3 N, f3 ac, f3 Q, f3 r, f3 m, float kc, PlTest &t) {
+  t.det = __builtin_fmaf(r.x, N.x, __builtin_fmaf(r.y, N.y, r.z * N.z));
+  const float rq = __builtin_fmaf(r.x, Q.x, __builtin_fmaf(r.y, Q.y, r.z * Q.z));
+  t.tp = __builtin_fmaf(m.x, ac.x, __builtin_fmaf(m.y, ac.y, __builtin_fmaf(m.z, ac.z, -rq)));
+  t.x1 = __builtin_fmaf(2.0f, t.tp, -t.det);
+  t.T = __builtin_fmaf(__builtin_fabsf(t.det), 1.00001f, kc);
+  return !(__builtin_fabsf(t.x1) > t.T);
 }
-// tri_exact: intersection.c:64-83 from the determinant test on, for the survivors; no early exits (it is rare).
-RT_D bool tri_exact(f3 ab, f3 ac, f3 r, float det, float tp, f3 tv, float &d, float &u, float &v) {
-  float inv = 1.0f / det;
-  u = tp * inv;
-  f3 q = cross3(tv, ab);
-  v = dot3(r, q) * inv;
-  d = dot3(ac, q) * inv;
-  // bitwise, not short-circuit: one compare chain, no control flow
-  return !((det > -0.000001f) & (det < 0.000001f)) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & !(d < 0.0f);
+// the other two slabs: 11 instructions
+RT_D bool pl_stage2(f3 ab, f3 P, f3 r, f3 m, PlTest &t) {
+  const float rp = __builtin_fmaf(r.x, P.x, __builtin_fmaf(r.y, P.y, r.z * P.z));
+  const float nv = __builtin_fmaf(m.x, ab.x, __builtin_fmaf(m.y, ab.y, __builtin_fmaf(m.z, ab.z, rp)));  // -vp
+  t.x2 = __builtin_fmaf(-2.0f, nv, -t.det);
+  t.x3 = __builtin_fmaf(2.0f, t.tp - nv, -t.det);
+  return !(__builtin_fmaxf(__builtin_fabsf(t.x2), __builtin_fabsf(t.x3)) > t.T);
+}
+RT_D bool pl_surely_inside(const PlTest &t, float kc) {
+  const float ad = __builtin_fabsf(t.det);
+  const float w = __builtin_fmaxf(__builtin_fabsf(t.x1), __builtin_fmaxf(__builtin_fabsf(t.x2), __builtin_fabsf(t.x3)));
+  return (w <= __builtin_fmaf(ad, 0.99999f, -kc)) & (ad - kc > 1.01e-6f);
+}
+// sign of det' is the sign of tri_test's det, and that one passes the 1e-6 test
+RT_D bool pl_sign_sure(const PlTest &t, float kc) { return __builtin_fabsf(t.det) - kc > 1.01e-6f; }
+// s * dp': the numerator of d with the sign of det' folded in
+RT_D float pl_sdist(f3 N, float an, f3 o, const PlTest &t) {
+  const float dp = __builtin_fmaf(-o.x, N.x, __builtin_fmaf(-o.y, N.y, __builtin_fmaf(-o.z, N.z, an)));
+  return __int_as_float(__float_as_int(dp) ^ (__float_as_int(t.det) & (int)0x80000000));
+}
+// Per-ray side of the filter: m = o x r (double, rounded once) and an upper bound of |o|.
+RT_D void pl_ray(f3 o, f3 r, f3 &m, float &onorm) {
+  const double ox = o.x, oy = o.y, oz = o.z, rx = r.x, ry = r.y, rz = r.z;
+  m = mk3((float)(oy * rz - oz * ry), (float)(oz * rx - ox * rz), (float)(ox * ry - oy * rx));
+  onorm = (float)sqrt(ox * ox + oy * oy + oz * oz) * 1.0001f;
 }
 
 // float -> uint32_t as the reference binary converts the tone-mapped channel (64-bit cvttss2si, low

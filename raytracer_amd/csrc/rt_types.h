@@ -11,18 +11,29 @@ constexpr int kPlanarSamples = 16; // src/raytrace.c:242
 
 struct f3 { float x, y, z; };
 
-// One triangle reference of a grid cell, self-contained so that a cell's list is a linear stream:
-// vertex i and the edges ij, ik (all that src/intersection.c:58-86 reads), the triangle index and the
-// transparency kt of its surface (what the shadow walk needs, src/voxelize.c:703).
+// One triangle reference of a grid cell, self-contained so that a cell's list is a linear stream: the
+// per-triangle constants of the staged filter (rt_math.h: n = ik x ij, ik, q = ik x i for the first slab;
+// ij, p = i x ij for the other two; an = i.n for the distance; vertices labelled so that ik is the longest
+// edge), the filter's error constants (the maxima over the batch of the cell's list the record belongs
+// to), the triangle index and the transparency kt of its surface (what the shadow walk needs,
+// src/voxelize.c:703).  The few triangles the filter cannot decide fetch i, ij, ik by index for tri_test.
 struct __attribute__((aligned(16))) TriRec {
-  float a[3];
-  float ab[3];
+  float n[3];
   float ac[3];
+  float q[3];
   int32_t id;
+  float k1, k2;
+  float ab[3];
+  float p[3];
+  float an;
   float kt;
-  int32_t pad;
 };
-static_assert(sizeof(TriRec) == 48, "TriRec is 48 bytes");
+static_assert(sizeof(TriRec) == 80, "TriRec is 80 bytes");
+constexpr int kRecFloats = 20;
+#ifndef RT_BATCH
+#define RT_BATCH 32
+#endif
+constexpr int kBatch = RT_BATCH; // records staged in LDS at a time; k1, k2 are maxima over such a batch
 
 // Uniform grid ("UDD", src/voxelize.h:21-25) plus the grown scene domain.
 struct GridP {
@@ -31,6 +42,9 @@ struct GridP {
   int32_t ncells;
   const uint32_t *cell_start;  // ncells+1 offsets into cell_tris
   const TriRec *cell_tris;
+  const float *geom;           // per triangle i, ij, ik (9 floats)
+  const float *filt;           // per triangle kRecFloats floats: a TriRec with the triangle's own k1, k2
+  float lmax;                  // longest triangle edge of the scene (upper bound)
 };
 
 // A ray waiting for its nearest-hit walk.  i < 0 marks a lane without work:
@@ -89,9 +103,11 @@ struct Ctl {
   uint32_t ticket_nearest[kMaxLevels];
   uint32_t ticket_shadow[kMaxLevels];
   uint32_t pad;
-  unsigned long long stat[16];
+  unsigned long long stat[24];
 };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
-            kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests, kStatCount };
+            kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests,
+            kNearStage2, kNearStage3, kNearExact, kShadStage2, kShadStage3, kShadExact,
+            kNearVisits, kShadVisits, kStatCount };
 
 }  // namespace rt

@@ -43,7 +43,7 @@ struct rtgpu_ctx {
   int tex_tri[4] = {-1, -1, -1, -1};
   int fan = 0, levels = 1;
   // scene, device side
-  float *d_verts = nullptr, *d_geom = nullptr, *d_aux = nullptr;
+  float *d_verts = nullptr, *d_geom = nullptr, *d_aux = nullptr, *d_filt = nullptr;
   int32_t *d_sid = nullptr, *d_box = nullptr, *d_refs = nullptr, *d_rand = nullptr;
   SurfaceD *d_surf = nullptr;
   LightD *d_lights = nullptr;
@@ -51,6 +51,9 @@ struct rtgpu_ctx {
   uint32_t *d_counts = nullptr, *d_cell_start = nullptr;
   TriRec *d_recs = nullptr;
   size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
+  float lmax = 0.0f;         // longest triangle edge of the uploaded scene
+  int64_t known_nrefs = -1;  // reference count of the uploaded scene's grid (it does not depend on the camera)
+  int known_nv[3] = {0, 0, 0};
   // frame
   CameraD cam = {};
   GridP grid = {};
@@ -241,7 +244,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   resolve_spans(c);
-  dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_sid); dev_free(&c->d_box);
+  dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
@@ -277,6 +280,7 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   for (int t = 0; t < s->nt; t++)
     if (s->sid[t] < 0 || s->sid[t] >= s->ns) return fail(c, RTGPU_E_NOT_ENOUGH_SURFACES, "surface id out of range");
   c->have_scene = c->have_frame = false;
+  c->known_nrefs = -1;
   c->nt = s->nt; c->ns = s->ns; c->nl = s->nl; c->npl = s->npl;
   c->lights.assign(s->lights, s->lights + s->nl);
   c->surfaces.assign(s->surfaces, s->surfaces + s->ns);
@@ -294,6 +298,18 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
       seen++;
     }
   }
+  // longest triangle edge of the scene, from the float edges the kernels compute with (the filter's distance bound)
+  double lmax = 0.0;
+  for (int t = 0; t < s->nt; t++) {
+    const float *v = s->vertices + 9 * (size_t)t;
+    double e[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 3; k++) {
+      const double ab = (double)(float)(v[3 + k] - v[k]), ac = (double)(float)(v[6 + k] - v[k]);
+      e[0] += ab * ab; e[1] += ac * ac; e[2] += (ac - ab) * (ac - ab);
+    }
+    for (int k = 0; k < 3; k++) if (e[k] > lmax) lmax = e[k];  // a NaN edge never wins; NaN triangles end in the exact test anyway
+  }
+  c->lmax = (float)(sqrt(lmax) * 1.001);
   // Secondary rays: a hit spawns a reflected ray if kr > 0 and a refracted one if kt > 0 (raytrace.c:193-204).
   // Only surfaces some triangle uses can spawn anything.
   std::vector<char> used(s->ns, 0);
@@ -311,7 +327,7 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
                                          "order of secondary hits is not implemented");
   int rc;
   if ((rc = dev_alloc(c, &c->d_verts, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->d_geom, (size_t)s->nt * 9)) ||
-      (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
+      (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_filt, (size_t)s->nt * kRecFloats)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
       (rc = dev_alloc(c, &c->d_box, (size_t)s->nt * 6)) || (rc = dev_alloc(c, &c->d_surf, (size_t)s->ns)) ||
       (rc = dev_alloc(c, &c->d_lights, (size_t)s->nl)) || (rc = dev_alloc(c, &c->d_planar, (size_t)s->npl)))
     return rc;
@@ -375,11 +391,12 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   }
   GridP g;
   for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
-  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr;
+  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax;
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
     Span sp(c, W_PRE);
-    hipLaunchKernelGGL(k_preprocess, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, f3{cam->ob[0], cam->ob[1], cam->ob[2]}, c->d_geom, c->d_aux);
+    hipLaunchKernelGGL(k_preprocess, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, f3{cam->ob[0], cam->ob[1], cam->ob[2]}, c->d_sid, c->d_surf,
+                       c->d_geom, c->d_aux, c->d_filt);
   }
   uint32_t nrefs = 0;
   {
@@ -387,15 +404,23 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), c->stream));
     hipLaunchKernelGGL(k_tri_boxes, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, g, c->d_box, c->d_counts);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_counts, c->d_cell_start);
-    HIPCHK(c, hipMemcpyAsync(&nrefs, c->d_cell_start + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // The grid depends on the scene and its lights only, so the reference count is read back (a host sync)
+    // for the first frame of a scene and reused afterwards; the lists themselves are rebuilt every frame.
+    if (c->known_nrefs >= 0 && c->known_nv[0] == nv[0] && c->known_nv[1] == nv[1] && c->known_nv[2] == nv[2]) {
+      nrefs = (uint32_t)c->known_nrefs;
+    } else {
+      HIPCHK(c, hipMemcpyAsync(&nrefs, c->d_cell_start + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->known_nrefs = nrefs;
+      for (int k = 0; k < 3; k++) c->known_nv[k] = nv[k];
+    }
     if ((size_t)nrefs > c->cap_refs) {
       if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs))) return rc;
       c->cap_refs = nrefs;
     }
     g.cell_tris = c->d_recs;
-    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_geom, c->d_sid,
-                       c->d_surf, c->d_recs, c->d_refs);
+    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs, c->d_refs);
+    hipLaunchKernelGGL(k_grid_kmax, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, g, c->d_recs);
   }
   HIPCHK(c, hipGetLastError());
   c->grid = g;
@@ -558,6 +583,9 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   out->shadow_steps = (int64_t)h[kShadS]; out->shadow_tests = (int64_t)h[kShadT];
   out->nearest_lane_tests = (int64_t)h[kNearLaneTests]; out->nearest_lane_slots = (int64_t)h[kNearWaveTests];
   out->shadow_lane_tests = (int64_t)h[kShadLaneTests]; out->shadow_lane_slots = (int64_t)h[kShadWaveTests];
+  out->nearest_stage2 = (int64_t)h[kNearStage2]; out->nearest_stage3 = (int64_t)h[kNearStage3]; out->nearest_exact = (int64_t)h[kNearExact];
+  out->shadow_stage2 = (int64_t)h[kShadStage2]; out->shadow_stage3 = (int64_t)h[kShadStage3]; out->shadow_exact = (int64_t)h[kShadExact];
+  out->nearest_visits = (int64_t)h[kNearVisits]; out->shadow_visits = (int64_t)h[kShadVisits];
   return RTGPU_OK;
 }
 
