@@ -176,6 +176,7 @@ def main():
         out["walk_stats_rank0"] = {
             f: {"simd_efficiency": ratio(cnt[f + "_lane_tests"], cnt[f + "_lane_slots"]),
                 "wave_tests": cnt[f + "_lane_slots"] // 64, "wave_cell_visits": cnt[f + "_visits"],
+                "batches_culled": ratio(cnt[f + "_batches_culled"], cnt[f + "_batches"]),
                 "reached_second_slabs": ratio(cnt[f + "_stage2"], cnt[f + "_lane_slots"] / 64),
                 "reached_distance_stage": ratio(cnt[f + "_stage3"], cnt[f + "_lane_slots"] / 64),
                 "reached_exact_test": ratio(cnt[f + "_exact"], cnt[f + "_lane_slots"] / 64)}

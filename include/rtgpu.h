@@ -104,6 +104,9 @@ typedef struct rtgpu_counters {
   int64_t nearest_stage2, nearest_stage3, nearest_exact, shadow_stage2, shadow_stage3, shadow_exact;
   /* Cell visits of the wavefronts: iterations of the walk kernels' outer loop (only with "count" = 1). */
   int64_t nearest_visits, shadow_visits;
+  /* Batches of 16 listed triangles the cell-mode walks looked at, and how many of them were skipped because
+   * no ray of the wavefront could meet the batch's bounding sphere (only with "count" = 1). */
+  int64_t nearest_batches, nearest_batches_culled, shadow_batches, shadow_batches_culled;
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP

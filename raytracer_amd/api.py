@@ -57,7 +57,8 @@ class Counters(C.Structure):
                                          "nearest_steps", "nearest_tests", "shadow_steps", "shadow_tests",
                                          "nearest_lane_tests", "nearest_lane_slots", "shadow_lane_tests",
                                          "shadow_lane_slots", "nearest_stage2", "nearest_stage3", "nearest_exact",
-                                         "shadow_stage2", "shadow_stage3", "shadow_exact", "nearest_visits", "shadow_visits")]
+                                         "shadow_stage2", "shadow_stage3", "shadow_exact", "nearest_visits", "shadow_visits", "nearest_batches",
+                                         "nearest_batches_culled", "shadow_batches", "shadow_batches_culled")]
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

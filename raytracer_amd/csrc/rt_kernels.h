@@ -48,53 +48,99 @@ RT_D bool wave_any(bool p) {
   return m != 0;
 }
 
-// pass1(record) is the side-effect-free first stage of the test (true = this lane cannot reject the
-// triangle yet); it is evaluated for RT_UNROLL records at a time, and only if it holds in some lane for
-// some of them does the wavefront leave the straight-line path and run the full test f(record, index)
-// on those records, in list order, checking more() after each.
-template <typename B, typename P, typename F, typename G>
-RT_D void stream_cell(const TriRec *__restrict__ recs, uint32_t beg, uint32_t end, float *slice, int lane, B &&batch,
+// Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
+// batch cull(centre, radius, transparent) decides, for the whole wavefront, whether any of its rays can
+// meet the batch's bounding sphere; only then are the batch's records staged and tested:
+//   batch(k1, k2)      once per surviving batch, with the batch's filter constants
+//   pass1(record)      the side-effect-free first stage of the test (true = this lane cannot reject the
+//                      triangle yet), evaluated for RT_UNROLL records at a time; only if it holds in some
+//                      lane for some of them does the wavefront leave the straight-line path and run
+//   f(record, index)   the full test on those records, in list order, checking
+//   more()             (wave-uniform) after each: false = stop.
+RT_D void stage_batch(const TriRec *__restrict__ recs, uint32_t c0, int n, float *rs, int lane) {
+  const int nvec = n * kRecVecs;
+  const float4 *src = reinterpret_cast<const float4 *>(recs + c0);
+  // global -> LDS without passing through registers: lane L's 16 bytes land at base + 16 L
+  static_assert(kStageLoads <= 5, "staging is written out for up to five loads per lane");
+  if (lane < nvec) glds16(src + lane, rs);
+  if (kStageLoads > 1 && lane + 64 < nvec) glds16(src + lane + 64, rs + 256);
+  if (kStageLoads > 2 && lane + 128 < nvec) glds16(src + lane + 128, rs + 512);
+  if (kStageLoads > 3 && lane + 192 < nvec) glds16(src + lane + 192, rs + 768);
+  if (kStageLoads > 4 && lane + 256 < nvec) glds16(src + lane + 256, rs + 1024);
+}
+RT_D void wait_staged() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename C, typename B, typename P, typename F, typename G>
+RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, float *slice, int lane, C &&cull, B &&batch,
                       P &&pass1, F &&f, G &&more) {
-  for (uint32_t c0 = beg; c0 < end; c0 += kBatch) {
-    const int n = (int)(end - c0 < (uint32_t)kBatch ? end - c0 : (uint32_t)kBatch);
-    const int nvec = n * kRecVecs;
-    const float4 *src = reinterpret_cast<const float4 *>(recs + c0);
-    // global -> LDS without passing through registers: lane L's 16 bytes land at base + 16 L
-    static_assert(kStageLoads <= 5, "staging is written out for up to five loads per lane");
-    if (lane < nvec) glds16(src + lane, slice);
-    if (kStageLoads > 1 && lane + 64 < nvec) glds16(src + lane + 64, slice + 256);
-    if (kStageLoads > 2 && lane + 128 < nvec) glds16(src + lane + 128, slice + 512);
-    if (kStageLoads > 3 && lane + 192 < nvec) glds16(src + lane + 192, slice + 768);
-    if (kStageLoads > 4 && lane + 256 < nvec) glds16(src + lane + 256, slice + 1024);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    batch(slice[10], slice[11]);
-    int j = 0;
-    for (; j + RT_UNROLL <= n; j += RT_UNROLL) {
-      unsigned long long m[RT_UNROLL], any = 0;
+  float *hs = slice;                             // kHdrChunk headers
+  float *rs = slice + kHdrChunk * kHdrFloats;    // kBatch records
+  const TriRec *__restrict__ recs = g.cell_tris;
+  const float4 *hsrc = reinterpret_cast<const float4 *>(g.cell_hdrs + g.hdr_start[cell]);
+  const uint32_t nb = (cnt + kBatch - 1) / kBatch;
+  for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
+    const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
+    static_assert(kHdrChunk * kHdrFloats / 4 == 64, "one 16-byte load per lane stages a header chunk");
+    if (lane < 2 * nh) glds16(hsrc + 2 * h0 + lane, hs);
+    wait_staged();
+    for (int b = 0; b < nh; ++b) {
+      const v4f h = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);
+      const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);
+      if (!cull(mk3(h.x, h.y, h.z), h.w, k.z)) continue;
+      const uint32_t c0 = beg + (h0 + (uint32_t)b) * kBatch;
+      const int n = (int)(beg + cnt - c0 < (uint32_t)kBatch ? beg + cnt - c0 : (uint32_t)kBatch);
+      stage_batch(recs, c0, n, rs, lane);
+      wait_staged();
+      batch(k.x, k.y);
+      int j = 0;
+      for (; j + RT_UNROLL <= n; j += RT_UNROLL) {
+        unsigned long long m[RT_UNROLL], any = 0;
 #pragma unroll
-      for (int q = 0; q < RT_UNROLL; q++) { m[q] = __ballot(pass1(slice + (j + q) * kRecFloats)); any |= m[q]; }
-      asm volatile("" : "+s"(any));
-      if (any != 0) {
-        asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into per-lane ones
+        for (int q = 0; q < RT_UNROLL; q++) { m[q] = __ballot(pass1(rs + (j + q) * kRecFloats)); any |= m[q]; }
+        asm volatile("" : "+s"(any));
+        if (any != 0) {
+          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into per-lane ones
 #pragma unroll
-        for (int q = 0; q < RT_UNROLL; q++) {
-          if (m[q] != 0) {
-            f(slice + (j + q) * kRecFloats, c0 + (uint32_t)(j + q));
-            if (!more()) return;
+          for (int q = 0; q < RT_UNROLL; q++) {
+            if (m[q] != 0) {
+              f(rs + (j + q) * kRecFloats, c0 + (uint32_t)(j + q));
+              if (!more()) return;
+            }
           }
         }
       }
-    }
-    for (; j < n; ++j) {
-      if (wave_any(pass1(slice + j * kRecFloats))) {
-        asm volatile("; some lane passed the first slab");
-        f(slice + j * kRecFloats, c0 + (uint32_t)j);
-        if (!more()) return;
+      for (; j < n; ++j) {
+        if (wave_any(pass1(rs + j * kRecFloats))) {
+          asm volatile("; some lane passed the first slab");
+          f(rs + j * kRecFloats, c0 + (uint32_t)j);
+          if (!more()) return;
+        }
       }
+      __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+constexpr int kSliceFloats = kHdrChunk * kHdrFloats + kBatch * kRecFloats;  // LDS floats per wavefront
+
+// Can the ray (r, m = o x r, odr = o.r, |o| <= onorm) meet a triangle of a batch within the parameter
+// range [0, tmax]?  false only if surely not: the line passes the sphere's centre at more than the radius,
+// or the sphere lies wholly behind the origin or wholly beyond tmax (a hit point of the batch lies inside
+// the sphere, so its ray parameter is within the radius of the centre's).  radius comes inflated by 0.1% +
+// 1e-5 |c| from k_grid_bounds; 1e-5 |o| is added here: two orders of magnitude above the rounding of these
+// few operations and of the exact test's own d.  A NaN compares false: not culled.
+RT_D bool sphere_may_hit(f3 c, float radius, f3 r, f3 m, float odr, float onorm, float tmax) {
+  const float R = __builtin_fmaf(0.00001f, onorm, radius);
+  const float ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
+  const float ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
+  const float ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
+  const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+  const float tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
+  const bool out = (d2 > R * R * 1.00001f) | (tc + R < 0.0f) | (tc - R > tmax);
+  return !out;
 }
 // Field access of a record in LDS or in memory (float index: n 0-2, ik 3-5, q 6-8, id 9, k1 10, k2 11,
 // ij 12-14, p 15-17, an 18, kt 19).  The first slab needs floats 0-8: two 16-byte reads and one 4-byte read.
@@ -177,12 +223,18 @@ RT_D f3 lane_bcast3(f3 v, int l) { return mk3(lane_bcast(v.x, l), lane_bcast(v.y
 #ifndef RT_LANE_MIN
 #define RT_LANE_MIN 8         // lane mode needs at least this many rays with short lists
 #endif
+#ifndef RT_CELL_COST
+#define RT_CELL_COST 6u       // cell mode's instructions per listed triangle, for the choice against ray mode
+#endif
 enum WalkMode { kCellMode = 0, kLaneMode = 1, kRayMode = 2 };
 RT_D int pick_mode(int group, uint32_t leader_cnt, int short_lanes) {
   if (group >= RT_CELL_MIN_GROUP) return kCellMode;
   if (short_lanes >= RT_LANE_MIN) return kLaneMode;
-  // the leader's group alone: cell mode costs cnt steps, ray mode group * (ceil(cnt/64) + 1 for the reduction)
-  return leader_cnt <= (uint32_t)group * ((leader_cnt + 63u) / 64u + 1u) ? kCellMode : kRayMode;
+  // The leader's group alone, in instructions the wavefront issues.  Cell mode: ~40 per batch header plus,
+  // for the batches that survive the culling (about a third), staging and kBatch tests of ~20: ~10 per
+  // listed triangle.  Ray mode, per ray of the group: ~80 per 64 triangles plus ~150 for the reduction.
+  const uint32_t ray_cost = (uint32_t)group * (((leader_cnt + 63u) / 64u) * 80u + 150u);
+  return leader_cnt * RT_CELL_COST <= ray_cost ? kCellMode : kRayMode;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,25 +372,67 @@ __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *_
     pos += __popcll(m);
   }
 }
-// Grid build, pass 3: the filter's error constants k1, k2 of every record are replaced by their maxima
-// over the record's batch (positions 64b .. 64b+63 of the cell's list), so that the cell-mode walk
-// needs one pair per batch.  One wavefront per cell.
-__global__ void __launch_bounds__(256) k_grid_kmax(GridP g, TriRec *__restrict__ recs) {
+// Grid build, pass 3: the header of every batch of kBatch consecutive records of a cell's list: bounding
+// sphere of the batch's triangles (vertices i, i+ij, i+ik as the exact test sees them), maxima of the
+// records' error constants, transparency flag.  One wavefront per cell, 64 / kBatch batches at a time.
+__global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restrict__ hdrs) {
   int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cell >= g.ncells) return;
   const uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
+  if (beg == end) return;
+  const uint32_t hbeg = g.hdr_start[cell];
   const int lane = lane_id();
-  for (uint32_t c0 = beg; c0 < end; c0 += kBatch) {
+  for (uint32_t c0 = beg; c0 < end; c0 += 64) {
     const uint32_t p = c0 + lane;
-    float k1 = 0.0f, k2 = 0.0f;
-    if (p < end) { k1 = recs[p].k1; k2 = recs[p].k2; }
+    const bool valid = p < end;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float k1 = 0.0f, k2 = 0.0f, transparent = 0.0f, bad = 0.0f;
+    if (valid) {
+      const TriRec &R = g.cell_tris[p];
+      k1 = R.k1; k2 = R.k2; transparent = R.kt > 0.0f ? 1.0f : 0.0f;
+      const float *G = g.geom + 9 * (long long)R.id;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      k1 = fmaxf(k1, __shfl_xor(k1, off));
-      k2 = fmaxf(k2, __shfl_xor(k2, off));
+      for (int q = 0; q < 3; q++) {
+        v[q] = G[q]; v[3 + q] = G[q] + G[3 + q]; v[6 + q] = G[q] + G[6 + q];
+        lo[q] = fminf(v[q], fminf(v[3 + q], v[6 + q]));
+        hi[q] = fmaxf(v[q], fmaxf(v[3 + q], v[6 + q]));
+      }
+#pragma unroll
+      for (int q = 0; q < 9; q++) if (!(fabsf(v[q]) < INFINITY)) bad = 1.0f;  // NaN or infinite vertex: never cull this batch
     }
-    if (p < end) { recs[p].k1 = k1; recs[p].k2 = k2; }
+#pragma unroll
+    for (int off = kBatch / 2; off > 0; off >>= 1) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off)); }
+      k1 = fmaxf(k1, __shfl_xor(k1, off)); k2 = fmaxf(k2, __shfl_xor(k2, off));
+      transparent = fmaxf(transparent, __shfl_xor(transparent, off)); bad = fmaxf(bad, __shfl_xor(bad, off));
+    }
+    const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+    float r2 = 0.0f;
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const float dx = v[3 * q] - cx, dy = v[3 * q + 1] - cy, dz = v[3 * q + 2] - cz;
+        r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
+      }
+    }
+#pragma unroll
+    for (int off = kBatch / 2; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off));
+    if (valid && (lane & (kBatch - 1)) == 0) {
+      BatchHdr h;
+      h.c[0] = cx; h.c[1] = cy; h.c[2] = cz;
+      const float cn = sqrtf(cx * cx + cy * cy + cz * cz);
+      h.radius = bad != 0.0f ? INFINITY : (sqrtf(r2) * 1.001f + 0.00001f * cn) * 1.0001f + 1e-30f;
+      h.k1 = k1; h.k2 = k2; h.transparent = transparent; h.pad = 0.0f;
+      hdrs[hbeg + (p - beg) / kBatch] = h;
+    }
   }
+}
+// Batches per cell, the input of the scan that gives hdr_start.
+__global__ void k_batch_counts(int ncells, const uint32_t *__restrict__ counts, uint32_t *__restrict__ nb) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ncells) nb[c] = (counts[c] + kBatch - 1) / kBatch;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,13 +480,16 @@ __global__ void __launch_bounds__(256) k_primary(CameraD cam, GridP g, int tile0
 template <bool COUNT>
 __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
                                                  Ctl *__restrict__ ctl, int level) {
-  __shared__ __attribute__((aligned(16))) float lds_batches[4][kBatch * kRecFloats];
+  __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   float *slice = lds_batches[threadIdx.x >> 6];
   const int lane = lane_id();
   const int nrays = ctl->count[level];
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
-  unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0;
+  unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
+#ifdef RT_DEBUG_MODES
+  unsigned long long dbgVisit[3] = {0, 0, 0}, dbgTests[3] = {0, 0, 0};
+#endif
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
   for (;;) {
     uint32_t base = 0;
@@ -407,9 +504,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     nPixels += __popcll(__ballot(ry.i != -2));
     nTraced += __popcll(__ballot(alive));
     const f3 o = ld3(ry.o), r = ld3(ry.r);
-    f3 pm = mk3(0.0f, 0.0f, 0.0f);  // o x r and |o|: the ray's side of the rejection filter
-    float onorm = 0.0f;
-    if (alive) pl_ray(o, r, pm, onorm);
+    f3 pm = mk3(0.0f, 0.0f, 0.0f);  // o x r, |o| and o.r: the ray's side of the filter and of the batch culling
+    float onorm = 0.0f, odr = 0.0f;
+    if (alive) pl_ray(o, r, pm, onorm, odr);
     Hit h;
     h.tri = alive ? -1 : -2;
     h.d = h.u = h.v = 0.0f; h.i = h.j = h.k = 0; h.pad = 0;
@@ -439,6 +536,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
+#ifdef RT_DEBUG_MODES
+      if (COUNT) { dbgVisit[mode]++; }
+#endif
       // exit distance of this voxel: a hit only counts if it lies before it (voxelize.c:569,574)
       float best = min3_ref(w.tx + w.dtx, w.ty + w.dty, w.tz + w.dtz);
       int best_id = -1;
@@ -466,12 +566,17 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       uint32_t nopos = 0;
       if (mode == kCellMode) {
         proc = in_group;
-        if (COUNT) { nWave += (unsigned long long)cnt; if (proc) nLane += cnt; }
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell(recs, beg, beg + cnt, slice, lane,
+        stream_cell(g, cell, beg, cnt, slice, lane,
+                    [&](f3 c, float radius, float) {
+                      const bool hit = wave_any(proc & sphere_may_hit(c, radius, r, pm, odr, onorm, best));
+                      if (COUNT) { nBatch++; nCull += !hit; }
+                      return hit;
+                    },
                     [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) : -INFINITY; },
                     [&](const float *R) {
+                      if (COUNT) { nWave++; if (proc) nLane++; }
                       const RecA A = rec_a(R);
                       PlTest t;
                       return pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
@@ -483,6 +588,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         const uint32_t pn = proc ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
+#ifdef RT_DEBUG_MODES
+          if (COUNT) dbgTests[1]++;
+#endif
           if (i < pn) {
             const float *R = reinterpret_cast<const float *>(recs + mybeg + i);
             test(R, o, r, pm, __builtin_fmaf(R[10], onorm, R[11]), ry.current, best, best_id, best_u, best_v, 0u, nopos);
@@ -500,6 +608,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         for (uint32_t t0 = beg; t0 < beg + cnt; t0 += 64) {
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
+#ifdef RT_DEBUG_MODES
+          if (COUNT) dbgTests[2]++;
+#endif
           if (t < beg + cnt) {
             const float *R = reinterpret_cast<const float *>(recs + t);
             test(R, lo, lr, lm, __builtin_fmaf(R[10], lon, R[11]), lcur, cb, cid, cu, cv, t, cpos);  // ascending t: earliest wins in a lane
@@ -551,7 +662,11 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       atomicAdd(&ctl->stat[kNearLaneTests], nLane); atomicAdd(&ctl->stat[kNearWaveTests], nWave * 64ull);
       atomicAdd(&ctl->stat[kNearestQ], nQ);
       atomicAdd(&ctl->stat[kNearStage2], nS2); atomicAdd(&ctl->stat[kNearStage3], nS3); atomicAdd(&ctl->stat[kNearExact], nEx);
-      atomicAdd(&ctl->stat[kNearVisits], nVisit);
+      atomicAdd(&ctl->stat[kNearVisits], nVisit); atomicAdd(&ctl->stat[kNearBatches], nBatch); atomicAdd(&ctl->stat[kNearCulled], nCull);
+#ifdef RT_DEBUG_MODES
+      atomicAdd(&ctl->stat[kNearStage2], dbgVisit[0] << 32); atomicAdd(&ctl->stat[kNearStage3], dbgVisit[1] << 32); atomicAdd(&ctl->stat[kNearExact], dbgVisit[2] << 32);
+      atomicAdd(&ctl->stat[kNearBatches], dbgTests[1] << 32); atomicAdd(&ctl->stat[kNearCulled], dbgTests[2] << 32);
+#endif
     }
   }
 }
@@ -689,14 +804,17 @@ template <bool COUNT>
 __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const Node *__restrict__ nodes,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
                                                 Ctl *__restrict__ ctl, int level, int node_base) {
-  __shared__ __attribute__((aligned(16))) float lds_batches[4][kBatch * kRecFloats];
+  __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   float *slice = lds_batches[threadIdx.x >> 6];
   const int lane = lane_id();
   const int n = ctl->count[level];
   const long long total = (long long)n * sp.nslots;
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
-  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0;
+  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
+#ifdef RT_DEBUG_MODES
+  unsigned long long dbgVisit[3] = {0, 0, 0}, dbgTests[3] = {0, 0, 0};
+#endif
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&ctl->ticket_shadow[level], 64u);
@@ -706,7 +824,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     bool alive = false;
     int slot = 0, nidx = 0, current = -1;
     f3 a = mk3(0, 0, 0), r = mk3(0, 0, 0), pm = mk3(0, 0, 0);  // pm = a x r, onorm >= |a|: the filter's ray side
-    float dmax = 0.0f, ts = 1.0f, result = 1.0f, onorm = 0.0f;
+    float dmax = 0.0f, ts = 1.0f, result = 1.0f, onorm = 0.0f, odr = 0.0f;
     bool have_result = false;
     Dda w;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -735,7 +853,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
 #pragma unroll
             for (int c = 0; c < 3; c++) { lo[c] = ai[c] < bi[c] ? ai[c] : bi[c]; hi[c] = ai[c] < bi[c] ? bi[c] : ai[c]; }
             dda_init(g, a, r, ai[0], ai[1], ai[2], w);
-            pl_ray(a, r, pm, onorm);
+            pl_ray(a, r, pm, onorm, odr);
             alive = true;
             if (COUNT) nW++;
             for (;;) {
@@ -760,6 +878,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
+#ifdef RT_DEBUG_MODES
+      if (COUNT) { dbgVisit[mode]++; }
+#endif
       bool proc;  // this lane's current cell is fully tested (or the ray blocked) after this step
       // One triangle for one shadow ray: 0 = no effect, 2 = accepted hit of a transparent triangle, 3 = opaque
       // blocker inside (1e-5, dmax); the filter decides what it can prove, tri_test the rest (:700-711).
@@ -793,7 +914,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell(recs, beg, beg + cnt, slice, lane,
+          stream_cell(g, cell, beg, cnt, slice, lane,
+                      [&](f3 c, float radius, float transparent) {
+                        // a transparent triangle attenuates wherever it is hit; an opaque one blocks only before the light
+                        const float tmax = transparent != 0.0f ? INFINITY : dmax;
+                        const bool hit = wave_any(in_group & (result >= 0.0f) & sphere_may_hit(c, radius, r, pm, odr, onorm, tmax));
+                        if (COUNT) { nBatch++; nCull += !hit; }
+                        return hit;
+                      },
                       [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) : -INFINITY; },
                       [&](const float *R) {
                         if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
@@ -818,6 +946,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         uint32_t pn = proc ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
+#ifdef RT_DEBUG_MODES
+          if (COUNT) dbgTests[1]++;
+#endif
           if (i < pn) {
             const float *R = reinterpret_cast<const float *>(recs + mybeg + i);
             test(R, a, r, pm, __builtin_fmaf(R[10], onorm, R[11]), current, dmax, [&](int verdict, float kt) {
@@ -838,6 +969,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         for (uint32_t t0 = beg; t0 < beg + cnt && !blocked; t0 += 64) {
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
+#ifdef RT_DEBUG_MODES
+          if (COUNT) dbgTests[2]++;
+#endif
           int verdict = 0;
           float kt = 0.0f;
           if (t < beg + cnt) {
@@ -875,7 +1009,11 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       atomicAdd(&ctl->stat[kShadS], nS); atomicAdd(&ctl->stat[kShadT], nT);
       atomicAdd(&ctl->stat[kShadowQ], nQ); atomicAdd(&ctl->stat[kShadowWalks], nW);
       atomicAdd(&ctl->stat[kShadStage2], nS2); atomicAdd(&ctl->stat[kShadStage3], nS3); atomicAdd(&ctl->stat[kShadExact], nEx);
-      atomicAdd(&ctl->stat[kShadVisits], nVisit);
+      atomicAdd(&ctl->stat[kShadVisits], nVisit); atomicAdd(&ctl->stat[kShadBatches], nBatch); atomicAdd(&ctl->stat[kShadCulled], nCull);
+#ifdef RT_DEBUG_MODES
+      atomicAdd(&ctl->stat[kShadStage2], dbgVisit[0] << 32); atomicAdd(&ctl->stat[kShadStage3], dbgVisit[1] << 32); atomicAdd(&ctl->stat[kShadExact], dbgVisit[2] << 32);
+      atomicAdd(&ctl->stat[kShadBatches], dbgTests[1] << 32); atomicAdd(&ctl->stat[kShadCulled], dbgTests[2] << 32);
+#endif
     }
   }
 }

@@ -229,11 +229,12 @@ RT_D float pl_sdist(f3 N, float an, f3 o, const PlTest &t) {
   const float dp = __builtin_fmaf(-o.x, N.x, __builtin_fmaf(-o.y, N.y, __builtin_fmaf(-o.z, N.z, an)));
   return __int_as_float(__float_as_int(dp) ^ (__float_as_int(t.det) & (int)0x80000000));
 }
-// Per-ray side of the filter: m = o x r (double, rounded once) and an upper bound of |o|.
-RT_D void pl_ray(f3 o, f3 r, f3 &m, float &onorm) {
+// Per-ray side of the filter: m = o x r (double, rounded once), an upper bound of |o|, and o.r.
+RT_D void pl_ray(f3 o, f3 r, f3 &m, float &onorm, float &odr) {
   const double ox = o.x, oy = o.y, oz = o.z, rx = r.x, ry = r.y, rz = r.z;
   m = mk3((float)(oy * rz - oz * ry), (float)(oz * rx - ox * rz), (float)(ox * ry - oy * rx));
   onorm = (float)sqrt(ox * ox + oy * oy + oz * oz) * 1.0001f;
+  odr = (float)(ox * rx + oy * ry + oz * rz);
 }
 
 // float -> uint32_t as the reference binary converts the tone-mapped channel (64-bit cvttss2si, low

@@ -14,15 +14,14 @@ struct f3 { float x, y, z; };
 // One triangle reference of a grid cell, self-contained so that a cell's list is a linear stream: the
 // per-triangle constants of the staged filter (rt_math.h: n = ik x ij, ik, q = ik x i for the first slab;
 // ij, p = i x ij for the other two; an = i.n for the distance; vertices labelled so that ik is the longest
-// edge), the filter's error constants (the maxima over the batch of the cell's list the record belongs
-// to), the triangle index and the transparency kt of its surface (what the shadow walk needs,
-// src/voxelize.c:703).  The few triangles the filter cannot decide fetch i, ij, ik by index for tri_test.
+// edge), the filter's error constants, the triangle index and the transparency kt of its surface (what
+// the shadow walk needs, src/voxelize.c:703).  The few triangles the filter cannot decide fetch i, ij, ik by index for tri_test.
 struct __attribute__((aligned(16))) TriRec {
   float n[3];
   float ac[3];
   float q[3];
   int32_t id;
-  float k1, k2;
+  float k1, k2;      // the triangle's own error constants
   float ab[3];
   float p[3];
   float an;
@@ -31,9 +30,24 @@ struct __attribute__((aligned(16))) TriRec {
 static_assert(sizeof(TriRec) == 80, "TriRec is 80 bytes");
 constexpr int kRecFloats = 20;
 #ifndef RT_BATCH
-#define RT_BATCH 32
+#define RT_BATCH 16
 #endif
-constexpr int kBatch = RT_BATCH; // records staged in LDS at a time; k1, k2 are maxima over such a batch
+constexpr int kBatch = RT_BATCH; // records per batch of a cell's list: the unit of culling and of LDS staging
+static_assert(kBatch == 8 || kBatch == 16 || kBatch == 32 || kBatch == 64, "a wavefront builds the bounds of 64 / kBatch batches at a time");
+constexpr int kHdrChunk = 32;    // batch headers staged in LDS at a time
+constexpr int kHdrFloats = 8;
+
+// Header of one batch (positions kBatch*b .. kBatch*b + kBatch-1 of a cell's list): a sphere that contains
+// every triangle of the batch (radius already inflated for rounding), the maxima of the records' k1, k2,
+// and whether any triangle of the batch is transparent (kt > 0).
+struct __attribute__((aligned(16))) BatchHdr {
+  float c[3];
+  float radius;
+  float k1, k2;
+  float transparent;
+  float pad;
+};
+static_assert(sizeof(BatchHdr) == 4 * kHdrFloats, "BatchHdr is 32 bytes");
 
 // Uniform grid ("UDD", src/voxelize.h:21-25) plus the grown scene domain.
 struct GridP {
@@ -42,6 +56,8 @@ struct GridP {
   int32_t ncells;
   const uint32_t *cell_start;  // ncells+1 offsets into cell_tris
   const TriRec *cell_tris;
+  const uint32_t *hdr_start;   // ncells+1 offsets into cell_hdrs (one header per kBatch records of a cell)
+  const BatchHdr *cell_hdrs;
   const float *geom;           // per triangle i, ij, ik (9 floats)
   const float *filt;           // per triangle kRecFloats floats: a TriRec with the triangle's own k1, k2
   float lmax;                  // longest triangle edge of the scene (upper bound)
@@ -103,11 +119,11 @@ struct Ctl {
   uint32_t ticket_nearest[kMaxLevels];
   uint32_t ticket_shadow[kMaxLevels];
   uint32_t pad;
-  unsigned long long stat[24];
+  unsigned long long stat[28];
 };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
             kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests,
             kNearStage2, kNearStage3, kNearExact, kShadStage2, kShadStage3, kShadExact,
-            kNearVisits, kShadVisits, kStatCount };
+            kNearVisits, kShadVisits, kNearBatches, kNearCulled, kShadBatches, kShadCulled, kStatCount };
 
 }  // namespace rt

@@ -48,7 +48,9 @@ struct rtgpu_ctx {
   SurfaceD *d_surf = nullptr;
   LightD *d_lights = nullptr;
   PlanarD *d_planar = nullptr;
-  uint32_t *d_counts = nullptr, *d_cell_start = nullptr;
+  uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr, *d_hdr_start = nullptr;
+  BatchHdr *d_hdrs = nullptr;
+  size_t cap_hdrs = 0;
   TriRec *d_recs = nullptr;
   size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
   float lmax = 0.0f;         // longest triangle edge of the uploaded scene
@@ -247,6 +249,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs);
+  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_hdrs);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->d_rank); dev_free(&c->d_ctl); dev_free(&c->d_totals);
@@ -386,12 +389,13 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   const int ncells = nv[0] * nv[1] * nv[2];
   int rc;
   if ((size_t)ncells + 1 > c->cap_cells) {
-    if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1)) ||
+        (rc = dev_alloc(c, &c->d_nbatch, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_hdr_start, (size_t)ncells + 1))) return rc;
     c->cap_cells = (size_t)ncells + 1;
   }
   GridP g;
   for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
-  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax;
+  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.cell_hdrs = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax;
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
     Span sp(c, W_PRE);
@@ -418,9 +422,18 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
       if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs))) return rc;
       c->cap_refs = nrefs;
     }
+    // one header per kBatch records of a cell: at most nrefs / kBatch full batches plus one partial batch per non-empty cell
+    const size_t nhdrs = (size_t)nrefs / kBatch + ((size_t)nrefs < (size_t)ncells ? (size_t)nrefs : (size_t)ncells) + 1;
+    if (nhdrs > c->cap_hdrs) {
+      if ((rc = dev_alloc(c, &c->d_hdrs, nhdrs))) return rc;
+      c->cap_hdrs = nhdrs;
+    }
     g.cell_tris = c->d_recs;
+    g.cell_hdrs = c->d_hdrs;
+    hipLaunchKernelGGL(k_batch_counts, dim3((ncells + 255) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_nbatch);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_nbatch, c->d_hdr_start);
     hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs, c->d_refs);
-    hipLaunchKernelGGL(k_grid_kmax, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, g, c->d_recs);
+    hipLaunchKernelGGL(k_grid_bounds, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, g, c->d_hdrs);
   }
   HIPCHK(c, hipGetLastError());
   c->grid = g;
@@ -586,6 +599,9 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   out->nearest_stage2 = (int64_t)h[kNearStage2]; out->nearest_stage3 = (int64_t)h[kNearStage3]; out->nearest_exact = (int64_t)h[kNearExact];
   out->shadow_stage2 = (int64_t)h[kShadStage2]; out->shadow_stage3 = (int64_t)h[kShadStage3]; out->shadow_exact = (int64_t)h[kShadExact];
   out->nearest_visits = (int64_t)h[kNearVisits]; out->shadow_visits = (int64_t)h[kShadVisits];
+  out->nearest_batches = (int64_t)h[kNearBatches]; out->nearest_batches_culled = (int64_t)h[kNearCulled];
+  out->shadow_batches = (int64_t)h[kShadBatches]; out->shadow_batches_culled = (int64_t)h[kShadCulled];
+  static_assert(kStatCount + kMaxLevels <= 32, "the totals buffer holds 32 counters");
   return RTGPU_OK;
 }
 
