@@ -48,15 +48,120 @@ RT_D bool wave_any(bool p) {
   return m != 0;
 }
 
-// Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
-// batch cull(centre, radius, transparent) decides, for the whole wavefront, whether any of its rays can
-// meet the batch's bounding sphere; only then are the batch's records staged and tested:
-//   batch(k1, k2)      once per surviving batch, with the batch's filter constants
-//   pass1(record)      the side-effect-free first stage of the test (true = this lane cannot reject the
-//                      triangle yet), evaluated for RT_UNROLL records at a time; only if it holds in some
-//                      lane for some of them does the wavefront leave the straight-line path and run
-//   f(record, index)   the full test on those records, in list order, checking
-//   more()             (wave-uniform) after each: false = stop.
+RT_D float lane_bcast(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+RT_D f3 lane_bcast3(f3 v, int l) { return mk3(lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)); }
+
+// Minima / maxima across lanes with DPP moves (no LDS traffic).  row_min16: every 16th lane (15, 31, 47, 63)
+// ends up with the minimum of its row of 16 lanes; wave_max: the maximum of all 64 lanes, in every lane.
+template <int CTRL, int ROW_MASK, bool MAX>
+RT_D float dpp_minmax(float x) {
+  const float y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+  return MAX ? fmaxf(x, y) : fminf(x, y);
+}
+template <bool MAX>
+RT_D float row_minmax16(float x) {
+  x = dpp_minmax<0x111, 0xf, MAX>(x);  // row_shr:1
+  x = dpp_minmax<0x112, 0xf, MAX>(x);  // row_shr:2
+  x = dpp_minmax<0x114, 0xf, MAX>(x);  // row_shr:4
+  x = dpp_minmax<0x118, 0xf, MAX>(x);  // row_shr:8
+  return x;
+}
+RT_D float wave_max(float x) {
+  x = row_minmax16<true>(x);
+  x = dpp_minmax<0x142, 0xa, true>(x);  // row_bcast:15 into rows 1 and 3
+  x = dpp_minmax<0x143, 0xc, true>(x);  // row_bcast:31 into rows 2 and 3
+  return lane_bcast(x, 63);
+}
+
+// The directions of the rays a wavefront walks through one cell: the leader's, and rho >= |r - axis| for
+// every ray of the group.
+struct Bundle { f3 axis; float rho; };
+RT_D Bundle make_bundle(bool in, f3 r, int leader) {
+  Bundle b;
+  b.axis = lane_bcast3(r, leader);
+  const f3 dr = sub3(r, b.axis);
+  // a NaN would be dropped by the max: it becomes +inf (nothing is culled for a group with such a ray)
+  float rho = in ? __builtin_amdgcn_sqrtf(dot3(dr, dr)) * 1.001f + 1e-7f : 0.0f;
+  if (!(rho >= 0.0f)) rho = INFINITY;
+  b.rho = wave_max(rho);
+  return b;
+}
+
+// For the batches of one header chunk and the rays of one bundle: an upper bound of 1 / |cos(ray, normal)|
+// over the batch's triangles, written into the LDS copy of each batch's header.  |cos| >= |axis.n| - rho for
+// the unit normal n.  A triangle the bundle may be coplanar with (bound below 1e-3) makes the batch's value
+// infinite: that batch is not culled in this visit.  One lane per record, 64 records per pass, the normals of
+// four passes loaded together (one memory latency); first = index of the chunk's first record, count = its records.
+struct NormalLoads { v4f x[4]; };
+RT_D NormalLoads normal_load4(const float *__restrict__ nrm, uint32_t first, uint32_t count, uint32_t p0, int lane) {
+  NormalLoads f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t p = p0 + 64u * q + (uint32_t)lane;
+    f.x[q] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    if (p < count) f.x[q] = *reinterpret_cast<const v4f *>(nrm + 4ull * (first + p));
+  }
+  return f;
+}
+RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t count, float *hs, int lane, const Bundle &bu,
+                    NormalLoads f0) {
+  static_assert(kBatch == 16, "a batch is one DPP row of 16 lanes");
+  NormalLoads f = f0;
+  for (uint32_t p0 = 0; p0 < count; p0 += 256) {
+    if (p0 != 0) f = normal_load4(nrm, first, count, p0, lane);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (p0 + 64u * q >= count) break;
+      const uint32_t p = p0 + 64u * q + (uint32_t)lane;
+      const v4f x = f.x[q];
+      float c0 = INFINITY;  // lanes past the end of the list do not count
+      if (p < count) {
+        c0 = __builtin_fabsf(bu.axis.x * x.x + bu.axis.y * x.y + bu.axis.z * x.z);
+        if (!(c0 >= 0.0f)) c0 = 0.0f;  // a NaN must not be dropped by the min below
+      }
+      c0 = row_minmax16<false>(c0);
+      const float cosb = c0 * 0.9999f - bu.rho;
+      const float inv = cosb > 0.001f ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
+      if ((lane & 15) == 15 && p - 15 < count) hs[(p / kBatch) * kHdrFloats + 7] = inv;  // the row's last lane holds its minimum
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Can the exact test report a hit of the ray (r, m = o x r, odr = o.r, |o| <= onorm) with a triangle of the
+// batch, with a ray parameter in [0, tmax]?  false only if surely not.  H is the batch header in LDS, its
+// inv_cos set by batch_cos for a bundle that contains this ray.
+//
+// Geometry: a hit point lies on the ray and in a triangle, all triangles lie in the sphere (c, radius), so the
+// ray passes the centre within the radius and the hit's parameter is within the radius of the centre's.
+// Rounding: what the exact test accepts is a point P whose barycentric coordinates are in [0,1] up to
+// eta = E / (2 |det|), with E <= 42 eps L |tv| + 19 eps L^2 the rounding of its numerators (rt_math.h; tv = o - i,
+// L the longest edge) and |det| = |n| |cos| for n = ij x ik and the angle between ray and normal.  P is within
+// 2 eta L of the triangle, and the reported d within (39 eps L^2 |tv| + 36 eps L^3) / |det| of P's parameter:
+//     (81 eps |tv| + 55 eps L) L^2 / (|n| |cos|)  <=  (gb tv + ga) / |cos|,   gb = k1 L / |n|,  ga = 0.4 gb L,  k1 = 144 eps L
+// (batch maxima of ga, gb from k_grid_bounds; tv = |o - c| + radius >= |o - i| for every triangle of the batch).
+// The radius grows by that much.  It comes inflated by 0.1% + 1e-5 |c| from k_grid_bounds and 1e-5 |o| is
+// added here for the rounding of these few operations.  A NaN compares false: not culled.
+RT_D bool sphere_may_hit(const float *H, float slack, f3 r, f3 m, float odr, float onorm, float tmax_opaque,
+                         bool transparent_counts_anywhere) {
+  const v4f h0 = *reinterpret_cast<const v4f *>(H);       // c, radius
+  const v4f h1 = *reinterpret_cast<const v4f *>(H + 4);   // k1, k2, transparent, inv_cos
+  const v2f h2 = *reinterpret_cast<const v2f *>(H + 8);   // ga, gb
+  const f3 c = mk3(h0.x, h0.y, h0.z);
+  const float ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
+  const float ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
+  const float ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
+  const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
+  const float tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
+  const float R0 = __builtin_fmaf(0.00001f, onorm, h0.w);
+  const float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(tc, tc, d2)), 1.001f, R0);  // |o - c|^2 = d2 + tc^2
+  const float R = __builtin_fmaf(__builtin_fmaf(h2.y, tv, h2.x), h1.w, R0) + slack;
+  // shadow walk: a transparent triangle attenuates wherever it is hit (d >= 0); an opaque one matters only before tmax_opaque
+  const float tmax = (transparent_counts_anywhere & (h1.z != 0.0f)) ? INFINITY : tmax_opaque;
+  const bool out = (d2 > R * R * 1.00001f) | (tc + R < 0.0f) | (tc - R > tmax);
+  return !out;
+}
+
 RT_D void stage_batch(const TriRec *__restrict__ recs, uint32_t c0, int n, float *rs, int lane) {
   const int nvec = n * kRecVecs;
   const float4 *src = reinterpret_cast<const float4 *>(recs + c0);
@@ -73,9 +178,18 @@ RT_D void wait_staged() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
+// batch cull(header) decides, for the whole wavefront, whether any of its rays can
+// meet the batch's bounding sphere; only then are the batch's records staged and tested:
+//   batch(k1, k2)      once per surviving batch, with the batch's filter constants
+//   pass1(record)      the side-effect-free first stage of the test (true = this lane cannot reject the
+//                      triangle yet), evaluated for RT_UNROLL records at a time; only if it holds in some
+//                      lane for some of them does the wavefront leave the straight-line path and run
+//   f(record, index)   the full test on those records, in list order, checking
+//   more()             (wave-uniform) after each: false = stop.
 template <typename C, typename B, typename P, typename F, typename G>
-RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, float *slice, int lane, C &&cull, B &&batch,
-                      P &&pass1, F &&f, G &&more) {
+RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
+                      C &&cull, B &&batch, P &&pass1, F &&f, G &&more) {
   float *hs = slice;                             // kHdrChunk headers
   float *rs = slice + kHdrChunk * kHdrFloats;    // kBatch records
   const TriRec *__restrict__ recs = g.cell_tris;
@@ -83,13 +197,19 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
   const uint32_t nb = (cnt + kBatch - 1) / kBatch;
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
     const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
-    static_assert(kHdrChunk * kHdrFloats / 4 == 64, "one 16-byte load per lane stages a header chunk");
-    if (lane < 2 * nh) glds16(hsrc + 2 * h0 + lane, hs);
-    wait_staged();
+    static_assert(kHdrChunk * kHdrFloats / 4 == 96, "two 16-byte loads per lane stage a header chunk");
+    if (lane < 3 * nh) glds16(hsrc + 3 * h0 + lane, hs);
+    if (lane + 64 < 3 * nh) glds16(hsrc + 3 * h0 + lane + 64, hs + 256);
+    {
+      const uint32_t first = h0 * kBatch, left = cnt - first;
+      const uint32_t count = left < (uint32_t)(kHdrChunk * kBatch) ? left : (uint32_t)(kHdrChunk * kBatch);
+      const NormalLoads f0 = normal_load4(g.cell_nrm, beg + first, count, 0u, lane);  // in flight together with the headers
+      wait_staged();
+      batch_cos(g.cell_nrm, beg + first, count, hs, lane, bundle, f0);
+    }
     for (int b = 0; b < nh; ++b) {
-      const v4f h = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);
       const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);
-      if (!cull(mk3(h.x, h.y, h.z), h.w, k.z)) continue;
+      if (!cull(hs + b * kHdrFloats)) continue;
       const uint32_t c0 = beg + (h0 + (uint32_t)b) * kBatch;
       const int n = (int)(beg + cnt - c0 < (uint32_t)kBatch ? beg + cnt - c0 : (uint32_t)kBatch);
       stage_batch(recs, c0, n, rs, lane);
@@ -126,31 +246,15 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
 }
 constexpr int kSliceFloats = kHdrChunk * kHdrFloats + kBatch * kRecFloats;  // LDS floats per wavefront
 
-// Can the ray (r, m = o x r, odr = o.r, |o| <= onorm) meet a triangle of a batch within the parameter
-// range [0, tmax]?  false only if surely not: the line passes the sphere's centre at more than the radius,
-// or the sphere lies wholly behind the origin or wholly beyond tmax (a hit point of the batch lies inside
-// the sphere, so its ray parameter is within the radius of the centre's).  radius comes inflated by 0.1% +
-// 1e-5 |c| from k_grid_bounds; 1e-5 |o| is added here: two orders of magnitude above the rounding of these
-// few operations and of the exact test's own d.  A NaN compares false: not culled.
-RT_D bool sphere_may_hit(f3 c, float radius, f3 r, f3 m, float odr, float onorm, float tmax) {
-  const float R = __builtin_fmaf(0.00001f, onorm, radius);
-  const float ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
-  const float ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
-  const float ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
-  const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
-  const float tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
-  const bool out = (d2 > R * R * 1.00001f) | (tc + R < 0.0f) | (tc - R > tmax);
-  return !out;
-}
-// Field access of a record in LDS or in memory (float index: n 0-2, ik 3-5, q 6-8, id 9, k1 10, k2 11,
-// ij 12-14, p 15-17, an 18, kt 19).  The first slab needs floats 0-8: two 16-byte reads and one 4-byte read.
+// Field access of a record in LDS or in memory (float index: n 0-2, k1 3, ik 4-6, q 7-9, id 10, k2 11,
+// ij 12-14, p 15-17, an 18, kt 19).  The first slab needs n, ik, q: two 16-byte reads and one 8-byte read.
 struct RecA { f3 n, ac, q; };
 struct RecB { f3 ab, p; float an, kt; };
 RT_D RecA rec_a(const float *R) {
   const v4f x = *reinterpret_cast<const v4f *>(R);
   const v4f y = *reinterpret_cast<const v4f *>(R + 4);
-  const float z = R[8];
-  RecA a; a.n = mk3(x.x, x.y, x.z); a.ac = mk3(x.w, y.x, y.y); a.q = mk3(y.z, y.w, z);
+  const v2f z = *reinterpret_cast<const v2f *>(R + 8);
+  RecA a; a.n = mk3(x.x, x.y, x.z); a.ac = mk3(y.x, y.y, y.z); a.q = mk3(y.w, z.x, z.y);
   return a;
 }
 RT_D RecB rec_b(const float *R) {
@@ -159,7 +263,7 @@ RT_D RecB rec_b(const float *R) {
   RecB b; b.ab = mk3(x.x, x.y, x.z); b.p = mk3(x.w, y.x, y.y); b.an = y.z; b.kt = y.w;
   return b;
 }
-RT_D int rec_id(const float *R) { return __float_as_int(R[9]); }
+RT_D int rec_id(const float *R) { return __float_as_int(R[10]); }
 // The exact test of a triangle the filter could not decide: i, ij, ik by index.
 RT_D bool exact_test(const GridP &g, int id, f3 o, f3 r, float &d, float &u, float &v) {
   const float *G = g.geom + 9 * (long long)id;
@@ -203,8 +307,6 @@ RT_D int shadow_verdict(const float *R, const RecA &A, PlTest &t, f3 o, f3 r, f3
   if (inside & in) return 3;
   return 1;
 }
-RT_D float lane_bcast(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
-RT_D f3 lane_bcast3(f3 v, int l) { return mk3(lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)); }
 
 // How a wavefront spends its lanes on triangle tests.  Three modes, chosen per step from what its
 // unfinished rays are standing in (all give the reference's result for every ray; only the order in
@@ -279,10 +381,10 @@ __global__ void k_preprocess(int nt, const float *__restrict__ verts, f3 ob, con
   const double eps = 5.9604644775390625e-8;  // 2^-24
   float *F = filt + kRecFloats * t;
   F[0] = (float)N[0]; F[1] = (float)N[1]; F[2] = (float)N[2];
-  F[3] = (float)ac2[0]; F[4] = (float)ac2[1]; F[5] = (float)ac2[2];
-  F[6] = (float)Q[0]; F[7] = (float)Q[1]; F[8] = (float)Q[2];
-  F[9] = __int_as_float(t);
-  F[10] = (float)(144.0 * eps * L * 1.001);
+  F[3] = (float)(144.0 * eps * L * 1.001);
+  F[4] = (float)ac2[0]; F[5] = (float)ac2[1]; F[6] = (float)ac2[2];
+  F[7] = (float)Q[0]; F[8] = (float)Q[1]; F[9] = (float)Q[2];
+  F[10] = __int_as_float(t);
   F[11] = (float)((144.0 * eps * L * amax + 56.0 * eps * L * L) * 1.001 + 1e-30);
   F[12] = (float)ab2[0]; F[13] = (float)ab2[1]; F[14] = (float)ab2[2];
   F[15] = (float)P[0]; F[16] = (float)P[1]; F[17] = (float)P[2];
@@ -345,7 +447,7 @@ __global__ void __launch_bounds__(1024) k_scan_cells(int n, const uint32_t *__re
 // appends those whose voxel box contains the cell; ballot + prefix count keeps the list in ascending
 // triangle order, which is the reference's insertion order and therefore its tie-break.
 __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *__restrict__ box, TriRec *__restrict__ recs,
-                                                   int32_t *__restrict__ refs) {
+                                                   int32_t *__restrict__ refs, float4 *__restrict__ nrm) {
   int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cell >= g.ncells) return;
   uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
@@ -368,6 +470,9 @@ __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *_
 #pragma unroll
       for (int q = 0; q < kRecVecs; q++) R[q] = F[q];
       refs[p] = t;
+      const float4 n = F[0];  // n, k1
+      const float inv = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+      nrm[p] = make_float4(n.x * inv, n.y * inv, n.z * inv, 0.0f);  // NaN for a degenerate triangle: its batch never culls
     }
     pos += __popcll(m);
   }
@@ -387,10 +492,15 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restri
     const bool valid = p < end;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float k1 = 0.0f, k2 = 0.0f, transparent = 0.0f, bad = 0.0f;
+    float k1 = 0.0f, k2 = 0.0f, transparent = 0.0f, bad = 0.0f, ga = 0.0f, gb = 0.0f;
     if (valid) {
       const TriRec &R = g.cell_tris[p];
       k1 = R.k1; k2 = R.k2; transparent = R.kt > 0.0f ? 1.0f : 0.0f;
+      // F = k1 (tv + 0.4 L) L / |n| = gb tv + ga  (see sphere_may_hit); L from k1 = 144 eps L
+      const float L = R.k1 * (1.0f / (144.0f * 5.9604644775390625e-8f));
+      gb = R.k1 * L / sqrtf(R.n[0] * R.n[0] + R.n[1] * R.n[1] + R.n[2] * R.n[2]) * 1.0001f;
+      ga = 0.4f * gb * L * 1.0001f;
+      if (!(gb >= 0.0f) || !(ga >= 0.0f)) bad = 1.0f;  // NaN (degenerate triangle): never cull this batch
       const float *G = g.geom + 9 * (long long)R.id;
 #pragma unroll
       for (int q = 0; q < 3; q++) {
@@ -406,6 +516,7 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restri
 #pragma unroll
       for (int q = 0; q < 3; q++) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off)); }
       k1 = fmaxf(k1, __shfl_xor(k1, off)); k2 = fmaxf(k2, __shfl_xor(k2, off));
+      ga = fmaxf(ga, __shfl_xor(ga, off)); gb = fmaxf(gb, __shfl_xor(gb, off));
       transparent = fmaxf(transparent, __shfl_xor(transparent, off)); bad = fmaxf(bad, __shfl_xor(bad, off));
     }
     const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
@@ -424,7 +535,8 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restri
       h.c[0] = cx; h.c[1] = cy; h.c[2] = cz;
       const float cn = sqrtf(cx * cx + cy * cy + cz * cz);
       h.radius = bad != 0.0f ? INFINITY : (sqrtf(r2) * 1.001f + 0.00001f * cn) * 1.0001f + 1e-30f;
-      h.k1 = k1; h.k2 = k2; h.transparent = transparent; h.pad = 0.0f;
+      h.k1 = k1; h.k2 = k2; h.transparent = transparent; h.inv_cos = INFINITY;
+      h.ga = ga; h.gb = gb; h.pad[0] = h.pad[1] = 0.0f;
       hdrs[hbeg + (p - beg) / kBatch] = h;
     }
   }
@@ -487,9 +599,6 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
   unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
-#ifdef RT_DEBUG_MODES
-  unsigned long long dbgVisit[3] = {0, 0, 0}, dbgTests[3] = {0, 0, 0};
-#endif
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
   for (;;) {
     uint32_t base = 0;
@@ -536,9 +645,6 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
-#ifdef RT_DEBUG_MODES
-      if (COUNT) { dbgVisit[mode]++; }
-#endif
       // exit distance of this voxel: a hit only counts if it lies before it (voxelize.c:569,574)
       float best = min3_ref(w.tx + w.dtx, w.ty + w.dty, w.tz + w.dtz);
       int best_id = -1;
@@ -568,13 +674,13 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell(g, cell, beg, cnt, slice, lane,
-                    [&](f3 c, float radius, float) {
-                      const bool hit = wave_any(proc & sphere_may_hit(c, radius, r, pm, odr, onorm, best));
+        stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(proc, r, leader),
+                    [&](const float *H) {
+                      const bool hit = wave_any(proc & sphere_may_hit(H, g.slack, r, pm, odr, onorm, best, false));
                       if (COUNT) { nBatch++; nCull += !hit; }
                       return hit;
                     },
-                    [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) : -INFINITY; },
+                    [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                     [&](const float *R) {
                       if (COUNT) { nWave++; if (proc) nLane++; }
                       const RecA A = rec_a(R);
@@ -588,12 +694,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         const uint32_t pn = proc ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
-#ifdef RT_DEBUG_MODES
-          if (COUNT) dbgTests[1]++;
-#endif
           if (i < pn) {
             const float *R = reinterpret_cast<const float *>(recs + mybeg + i);
-            test(R, o, r, pm, __builtin_fmaf(R[10], onorm, R[11]), ry.current, best, best_id, best_u, best_v, 0u, nopos);
+            test(R, o, r, pm, __builtin_fmaf(R[3], onorm, R[11]) + g.slack, ry.current, best, best_id, best_u, best_v, 0u, nopos);
           }
         }
       } else {
@@ -608,12 +711,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         for (uint32_t t0 = beg; t0 < beg + cnt; t0 += 64) {
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
-#ifdef RT_DEBUG_MODES
-          if (COUNT) dbgTests[2]++;
-#endif
           if (t < beg + cnt) {
             const float *R = reinterpret_cast<const float *>(recs + t);
-            test(R, lo, lr, lm, __builtin_fmaf(R[10], lon, R[11]), lcur, cb, cid, cu, cv, t, cpos);  // ascending t: earliest wins in a lane
+            test(R, lo, lr, lm, __builtin_fmaf(R[3], lon, R[11]) + g.slack, lcur, cb, cid, cu, cv, t, cpos);  // ascending t: earliest wins in a lane
           }
         }
         // smallest d, ties to the earliest list position: the reference's strict `d < dmin` scan order
@@ -663,10 +763,6 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       atomicAdd(&ctl->stat[kNearestQ], nQ);
       atomicAdd(&ctl->stat[kNearStage2], nS2); atomicAdd(&ctl->stat[kNearStage3], nS3); atomicAdd(&ctl->stat[kNearExact], nEx);
       atomicAdd(&ctl->stat[kNearVisits], nVisit); atomicAdd(&ctl->stat[kNearBatches], nBatch); atomicAdd(&ctl->stat[kNearCulled], nCull);
-#ifdef RT_DEBUG_MODES
-      atomicAdd(&ctl->stat[kNearStage2], dbgVisit[0] << 32); atomicAdd(&ctl->stat[kNearStage3], dbgVisit[1] << 32); atomicAdd(&ctl->stat[kNearExact], dbgVisit[2] << 32);
-      atomicAdd(&ctl->stat[kNearBatches], dbgTests[1] << 32); atomicAdd(&ctl->stat[kNearCulled], dbgTests[2] << 32);
-#endif
     }
   }
 }
@@ -812,9 +908,6 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
   unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
-#ifdef RT_DEBUG_MODES
-  unsigned long long dbgVisit[3] = {0, 0, 0}, dbgTests[3] = {0, 0, 0};
-#endif
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&ctl->ticket_shadow[level], 64u);
@@ -878,9 +971,6 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
-#ifdef RT_DEBUG_MODES
-      if (COUNT) { dbgVisit[mode]++; }
-#endif
       bool proc;  // this lane's current cell is fully tested (or the ray blocked) after this step
       // One triangle for one shadow ray: 0 = no effect, 2 = accepted hit of a transparent triangle, 3 = opaque
       // blocker inside (1e-5, dmax); the filter decides what it can prove, tri_test the rest (:700-711).
@@ -914,15 +1004,13 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell(g, cell, beg, cnt, slice, lane,
-                      [&](f3 c, float radius, float transparent) {
-                        // a transparent triangle attenuates wherever it is hit; an opaque one blocks only before the light
-                        const float tmax = transparent != 0.0f ? INFINITY : dmax;
-                        const bool hit = wave_any(in_group & (result >= 0.0f) & sphere_may_hit(c, radius, r, pm, odr, onorm, tmax));
+          stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(in_group, r, leader),
+                      [&](const float *H) {
+                        const bool hit = wave_any(in_group & (result >= 0.0f) & sphere_may_hit(H, g.slack, r, pm, odr, onorm, dmax, true));
                         if (COUNT) { nBatch++; nCull += !hit; }
                         return hit;
                       },
-                      [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) : -INFINITY; },
+                      [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                       [&](const float *R) {
                         if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
                         const RecA A = rec_a(R);
@@ -946,12 +1034,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         uint32_t pn = proc ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
-#ifdef RT_DEBUG_MODES
-          if (COUNT) dbgTests[1]++;
-#endif
           if (i < pn) {
             const float *R = reinterpret_cast<const float *>(recs + mybeg + i);
-            test(R, a, r, pm, __builtin_fmaf(R[10], onorm, R[11]), current, dmax, [&](int verdict, float kt) {
+            test(R, a, r, pm, __builtin_fmaf(R[3], onorm, R[11]) + g.slack, current, dmax, [&](int verdict, float kt) {
               if (verdict == 2) ts *= kt;
               else if (verdict == 3) { result = -1.0f; alive = false; pn = 0u; }
             });
@@ -969,14 +1054,11 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         for (uint32_t t0 = beg; t0 < beg + cnt && !blocked; t0 += 64) {
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
-#ifdef RT_DEBUG_MODES
-          if (COUNT) dbgTests[2]++;
-#endif
           int verdict = 0;
           float kt = 0.0f;
           if (t < beg + cnt) {
             const float *R = reinterpret_cast<const float *>(recs + t);
-            test(R, la, lr, lm, __builtin_fmaf(R[10], lon, R[11]), lcur, ldmax, [&](int vd, float k) { verdict = vd; kt = k; });
+            test(R, la, lr, lm, __builtin_fmaf(R[3], lon, R[11]) + g.slack, lcur, ldmax, [&](int vd, float k) { verdict = vd; kt = k; });
           }
           // the transparency product is taken in list order, like the reference's scan
           for (unsigned long long tm = __ballot(verdict == 2); tm != 0; tm &= tm - 1) cts *= lane_bcast(kt, __ffsll(tm) - 1);
@@ -1010,10 +1092,6 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       atomicAdd(&ctl->stat[kShadowQ], nQ); atomicAdd(&ctl->stat[kShadowWalks], nW);
       atomicAdd(&ctl->stat[kShadStage2], nS2); atomicAdd(&ctl->stat[kShadStage3], nS3); atomicAdd(&ctl->stat[kShadExact], nEx);
       atomicAdd(&ctl->stat[kShadVisits], nVisit); atomicAdd(&ctl->stat[kShadBatches], nBatch); atomicAdd(&ctl->stat[kShadCulled], nCull);
-#ifdef RT_DEBUG_MODES
-      atomicAdd(&ctl->stat[kShadStage2], dbgVisit[0] << 32); atomicAdd(&ctl->stat[kShadStage3], dbgVisit[1] << 32); atomicAdd(&ctl->stat[kShadExact], dbgVisit[2] << 32);
-      atomicAdd(&ctl->stat[kShadBatches], dbgTests[1] << 32); atomicAdd(&ctl->stat[kShadCulled], dbgTests[2] << 32);
-#endif
     }
   }
 }

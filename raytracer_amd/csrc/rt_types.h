@@ -18,10 +18,11 @@ struct f3 { float x, y, z; };
 // the shadow walk needs, src/voxelize.c:703).  The few triangles the filter cannot decide fetch i, ij, ik by index for tri_test.
 struct __attribute__((aligned(16))) TriRec {
   float n[3];
+  float k1;          // the triangle's own error constants: k1 here, next to n (what batch_fuzz reads), k2 below
   float ac[3];
   float q[3];
   int32_t id;
-  float k1, k2;      // the triangle's own error constants
+  float k2;
   float ab[3];
   float p[3];
   float an;
@@ -35,19 +36,23 @@ constexpr int kRecFloats = 20;
 constexpr int kBatch = RT_BATCH; // records per batch of a cell's list: the unit of culling and of LDS staging
 static_assert(kBatch == 8 || kBatch == 16 || kBatch == 32 || kBatch == 64, "a wavefront builds the bounds of 64 / kBatch batches at a time");
 constexpr int kHdrChunk = 32;    // batch headers staged in LDS at a time
-constexpr int kHdrFloats = 8;
+constexpr int kHdrFloats = 12;
 
 // Header of one batch (positions kBatch*b .. kBatch*b + kBatch-1 of a cell's list): a sphere that contains
 // every triangle of the batch (radius already inflated for rounding), the maxima of the records' k1, k2,
-// and whether any triangle of the batch is transparent (kt > 0).
+// whether any triangle of the batch is transparent (kt > 0), and the batch's constants ga, gb of the bound
+// of what rounding can add to the sphere (sphere_may_hit in rt_kernels.h).  inv_cos is scratch: the walk
+// kernels keep the visit's bound of 1 / |cos(ray, normal)| for the batch there, in their LDS copy.
 struct __attribute__((aligned(16))) BatchHdr {
   float c[3];
   float radius;
   float k1, k2;
   float transparent;
-  float pad;
+  float inv_cos;
+  float ga, gb;
+  float pad[2];
 };
-static_assert(sizeof(BatchHdr) == 4 * kHdrFloats, "BatchHdr is 32 bytes");
+static_assert(sizeof(BatchHdr) == 4 * kHdrFloats, "BatchHdr is 48 bytes");
 
 // Uniform grid ("UDD", src/voxelize.h:21-25) plus the grown scene domain.
 struct GridP {
@@ -58,9 +63,11 @@ struct GridP {
   const TriRec *cell_tris;
   const uint32_t *hdr_start;   // ncells+1 offsets into cell_hdrs (one header per kBatch records of a cell)
   const BatchHdr *cell_hdrs;
+  const float *cell_nrm;       // unit normal of every listed triangle (4 floats per reference, list order)
   const float *geom;           // per triangle i, ij, ik (9 floats)
   const float *filt;           // per triangle kRecFloats floats: a TriRec with the triangle's own k1, k2
   float lmax;                  // longest triangle edge of the scene (upper bound)
+  float slack;                 // 0, or +inf to switch the filter and the batch culling off (every test is then the exact one)
 };
 
 // A ray waiting for its nearest-hit walk.  i < 0 marks a lane without work:

@@ -33,6 +33,7 @@ struct rtgpu_ctx {
   bool opt_count = false, opt_timing = false;
   int64_t chunk_bytes = 8ll << 30;
   int waves_per_cu = 32;
+  bool filter = true;        // staged triangle filter + batch culling (off: every listed triangle gets the exact test)
   // scene, host side
   bool have_scene = false, have_frame = false;
   int nt = 0, ns = 0, nl = 0, npl = 0;
@@ -50,6 +51,7 @@ struct rtgpu_ctx {
   PlanarD *d_planar = nullptr;
   uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr, *d_hdr_start = nullptr;
   BatchHdr *d_hdrs = nullptr;
+  float4 *d_nrm = nullptr;
   size_t cap_hdrs = 0;
   TriRec *d_recs = nullptr;
   size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
@@ -249,7 +251,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs);
-  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_hdrs);
+  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->d_rank); dev_free(&c->d_ctl); dev_free(&c->d_totals);
@@ -270,6 +272,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   if (!strcmp(name, "count")) c->opt_count = value != 0;
   else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
+  else if (!strcmp(name, "filter")) c->filter = value != 0;
   else if (!strcmp(name, "waves_per_cu")) { if (value < 1 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
   return RTGPU_OK;
@@ -395,7 +398,7 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   }
   GridP g;
   for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
-  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.cell_hdrs = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax;
+  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.cell_hdrs = nullptr; g.cell_nrm = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
     Span sp(c, W_PRE);
@@ -419,7 +422,8 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
       for (int k = 0; k < 3; k++) c->known_nv[k] = nv[k];
     }
     if ((size_t)nrefs > c->cap_refs) {
-      if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs))) return rc;
+      if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs)) ||
+          (rc = dev_alloc(c, &c->d_nrm, (size_t)nrefs))) return rc;
       c->cap_refs = nrefs;
     }
     // one header per kBatch records of a cell: at most nrefs / kBatch full batches plus one partial batch per non-empty cell
@@ -430,9 +434,10 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     }
     g.cell_tris = c->d_recs;
     g.cell_hdrs = c->d_hdrs;
+    g.cell_nrm = reinterpret_cast<const float *>(c->d_nrm);
     hipLaunchKernelGGL(k_batch_counts, dim3((ncells + 255) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_nbatch);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_nbatch, c->d_hdr_start);
-    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs, c->d_refs);
+    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs, c->d_refs, c->d_nrm);
     hipLaunchKernelGGL(k_grid_bounds, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, g, c->d_hdrs);
   }
   HIPCHK(c, hipGetLastError());
@@ -493,6 +498,7 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
   if ((int64_t)chunk * kTilePixels * (c->fan > 1 ? 16 : 1) > 0x7fffffffll) chunk = 0x7fffffffll / (kTilePixels * (c->fan > 1 ? 16 : 1));
   int rc = ensure_chunk(c, (size_t)chunk);
   if (rc) return rc;
+  c->grid.slack = c->filter ? 0.0f : INFINITY;
   const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
   for (int64_t t0 = 0; t0 < ntiles; t0 += chunk) {
     const int nt_chunk = (int)((ntiles - t0) < chunk ? (ntiles - t0) : chunk);

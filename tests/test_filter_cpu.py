@@ -1,0 +1,266 @@
+"""The walk kernels' staged triangle filter, restated in numpy and checked against the exact test.
+
+The HIP kernels put a conservative filter (raytracer_amd/csrc/rt_math.h: pl_stage1, pl_stage2,
+pl_surely_inside, pl_sdist; rt_kernels.h: nearest_needs_exact, shadow_verdict, sphere_may_hit) in front
+of the reference's Moeller-Trumbore test (src/intersection.c:58-86).  The filter must never decide
+differently from that test.  Here both are evaluated in float32 on millions of rays, most of them aimed
+at the places where rounding decides (triangle edges and vertices, grazing incidence, slivers, origins
+far from the triangle), and every implication the kernels rely on is asserted:
+
+    exact test accepts              =>  no slab stage rejects, the batch sphere is not culled
+    "surely inside" + sign sure     =>  exact det/u/v tests accept
+    distance verdicts               =>  agree with the exact d
+
+float32 FMA is emulated as float32(float64(a) * float64(b) + float64(c)) (exact product, one extra
+rounding of the sum in rare ties: a last-bit effect, orders of magnitude below the margins under test).
+"""
+import numpy as np
+import pytest
+
+F = np.float32
+EPS = 5.9604644775390625e-8
+
+
+def fma(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+
+
+def cross32(a, b):  # vectormath.h:87-92, float32, no FMA
+    return np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2],
+                     a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], 1)
+
+
+def dot32(a, b):  # vectormath.h:95-97
+    return a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1] + a[:, 2] * b[:, 2]
+
+
+def exact_test(a, ab, ac, o, r):
+    """src/intersection.c:58-86 without the early returns: accept mask and d, u, v, det."""
+    with np.errstate(all="ignore"):
+        p = cross32(r, ac)
+        det = dot32(ab, p)
+        ok_det = ~((det > F(-0.000001)) & (det < F(0.000001)))
+        inv = F(1.0) / det
+        tv = o - a
+        u = dot32(tv, p) * inv
+        ok_u = ~((u < 0) | (u > 1))
+        q = cross32(tv, ab)
+        v = dot32(r, q) * inv
+        ok_v = ~((v < 0) | (u + v > 1))
+        d = dot32(ac, q) * inv
+        ok_d = ~(d < 0)
+    return ok_det & ok_u & ok_v & ok_d, ok_det & ok_u & ok_v, d, u, v, det
+
+
+def preprocess(a, ab, ac):
+    """k_preprocess's filter record: relabelled (longest edge = ik), double arithmetic, rounded once."""
+    A, AB, AC = a.astype(np.float64), ab.astype(np.float64), ac.astype(np.float64)
+    B, C, BC = A + AB, A + AC, AC - AB
+    lab, lac, lbc = (np.linalg.norm(x, axis=1) for x in (AB, AC, BC))
+    keep = (lac >= lab) & (lac >= lbc)
+    swap = ~keep & (lab >= lbc)
+    a2 = np.where((keep | swap)[:, None], A, B)
+    ab2 = np.where(keep[:, None], AB, np.where(swap[:, None], AC, -AB))
+    ac2 = np.where(keep[:, None], AC, np.where(swap[:, None], AB, BC))
+    N, Q, P = np.cross(ac2, ab2), np.cross(ac2, a2), np.cross(a2, ab2)
+    L = np.maximum(lab, np.maximum(lac, lbc))
+    amax = np.maximum(np.linalg.norm(A, axis=1), np.maximum(np.linalg.norm(B, axis=1), np.linalg.norm(C, axis=1)))
+    k1 = (144.0 * EPS * L * 1.001).astype(F)
+    k2 = ((144.0 * EPS * L * amax + 56.0 * EPS * L * L) * 1.001 + 1e-30).astype(F)
+    an = np.einsum("ij,ij->i", a2, N).astype(F)
+    verts = np.stack([A, B, C], 1)
+    return dict(N=N.astype(F), ac=ac2.astype(F), Q=Q.astype(F), ab=ab2.astype(F), P=P.astype(F), an=an, k1=k1, k2=k2,
+                L=L, verts=verts)
+
+
+def ray_side(o, r):
+    O, R = o.astype(np.float64), r.astype(np.float64)
+    m = np.cross(O, R).astype(F)
+    onorm = np.linalg.norm(O, axis=1).astype(F) * F(1.0001)
+    odr = np.einsum("ij,ij->i", O, R).astype(F)
+    return m, onorm, odr
+
+
+def stages(T, o, r, m, kc):
+    N, ac, Q, ab, P = T["N"], T["ac"], T["Q"], T["ab"], T["P"]
+    det = fma(r[:, 0], N[:, 0], fma(r[:, 1], N[:, 1], r[:, 2] * N[:, 2]))
+    rq = fma(r[:, 0], Q[:, 0], fma(r[:, 1], Q[:, 1], r[:, 2] * Q[:, 2]))
+    tp = fma(m[:, 0], ac[:, 0], fma(m[:, 1], ac[:, 1], fma(m[:, 2], ac[:, 2], -rq)))
+    x1 = fma(np.full_like(tp, 2), tp, -det)
+    Tt = fma(np.abs(det), np.full_like(det, F(1.00001)), kc)
+    p1 = ~(np.abs(x1) > Tt)
+    rp = fma(r[:, 0], P[:, 0], fma(r[:, 1], P[:, 1], r[:, 2] * P[:, 2]))
+    nv = fma(m[:, 0], ab[:, 0], fma(m[:, 1], ab[:, 1], fma(m[:, 2], ab[:, 2], rp)))
+    x2 = fma(np.full_like(nv, -2), nv, -det)
+    x3 = fma(np.full_like(nv, 2), tp - nv, -det)
+    p2 = ~(np.maximum(np.abs(x2), np.abs(x3)) > Tt)
+    ad = np.abs(det)
+    w = np.maximum(np.abs(x1), np.maximum(np.abs(x2), np.abs(x3)))
+    inside = (w <= fma(ad, np.full_like(ad, F(0.99999)), -kc)) & (ad - kc > F(1.01e-6))
+    sure = ad - kc > F(1.01e-6)
+    dp = fma(-o[:, 0], N[:, 0], fma(-o[:, 1], N[:, 1], fma(-o[:, 2], N[:, 2], T["an"])))
+    sd = np.where(det < 0, -dp, dp)
+    return p1, p2, inside, sure, sd, ad
+
+
+def batch_header(T):
+    """k_grid_bounds for a batch of one triangle, float32 like the kernel."""
+    verts = T["verts"].astype(F)
+    lo, hi = verts.min(1), verts.max(1)
+    c = (F(0.5) * (lo + hi)).astype(F)
+    r2 = ((verts - c[:, None, :]) ** 2).sum(2).max(1).astype(F)
+    cn = np.sqrt((c * c).sum(1)).astype(F)
+    radius = ((np.sqrt(r2) * F(1.001) + F(0.00001) * cn) * F(1.0001) + F(1e-30)).astype(F)
+    N = T["N"]
+    with np.errstate(all="ignore"):
+        nn = np.sqrt(N[:, 0] * N[:, 0] + N[:, 1] * N[:, 1] + N[:, 2] * N[:, 2]).astype(F)
+        L = T["k1"] * F(1.0 / (144.0 * EPS))
+        gb = (T["k1"] * L / nn * F(1.0001)).astype(F)
+        ga = (F(0.4) * gb * L * F(1.0001)).astype(F)
+        nrm = (N * (F(1.0) / nn)[:, None]).astype(F)
+    bad = ~((gb >= 0) & (ga >= 0))
+    radius = np.where(bad, F(np.inf), radius)
+    return dict(c=c, radius=radius, ga=ga, gb=gb, nrm=nrm)
+
+
+def batch_cos(H, axis, rho):
+    """batch_cos of rt_kernels.h for batches of one triangle: bound of 1 / |cos(ray, normal)| over a bundle."""
+    n = H["nrm"]
+    with np.errstate(all="ignore"):
+        c0 = np.abs(axis[:, 0] * n[:, 0] + axis[:, 1] * n[:, 1] + axis[:, 2] * n[:, 2])
+        c0 = np.where(c0 >= 0, c0, F(0))
+        cosb = c0 * F(0.9999) - rho
+        return np.where(cosb > F(0.001), (F(1.0) / cosb).astype(F) * F(1.01), F(np.inf)).astype(F)
+
+
+def sphere_may_hit(H, inv_cos, r, m, odr, onorm, tmax):
+    c = H["c"]
+    with np.errstate(all="ignore"):
+        ex = fma(-c[:, 2], r[:, 1], fma(c[:, 1], r[:, 2], -m[:, 0]))
+        ey = fma(-c[:, 0], r[:, 2], fma(c[:, 2], r[:, 0], -m[:, 1]))
+        ez = fma(-c[:, 1], r[:, 0], fma(c[:, 0], r[:, 1], -m[:, 2]))
+        d2 = fma(ex, ex, fma(ey, ey, ez * ez))
+        tc = fma(c[:, 0], r[:, 0], fma(c[:, 1], r[:, 1], fma(c[:, 2], r[:, 2], -odr)))
+        R0 = fma(np.full_like(onorm, F(0.00001)), onorm, H["radius"])
+        tv = fma(np.sqrt(fma(tc, tc, d2)), np.full_like(tc, F(1.001)), R0)
+        R = fma(fma(H["gb"], tv, H["ga"]), inv_cos, R0)
+        out = (d2 > R * R * F(1.00001)) | (tc + R < 0) | (tc - R > tmax)
+    return ~out
+
+
+def make_cases(rng, n, scale, offset, aim):
+    """Triangles of size ~scale around `offset`; rays from origins up to 30 scales away, aimed at a point
+    of the triangle's plane chosen by `aim` (barycentric coordinates), then normalised like the kernels do."""
+    a = (rng.standard_normal((n, 3)) * scale + offset).astype(F)
+    shape = rng.random(n)
+    ab = (rng.standard_normal((n, 3)) * scale).astype(F)
+    ac = (rng.standard_normal((n, 3)) * scale).astype(F)
+    sliver = shape < 0.15  # nearly collinear edges
+    ac = np.where(sliver[:, None], (ab * (rng.random((n, 1)) * 2 + 0.1).astype(F) + ac * F(1e-3)).astype(F), ac)
+    u, v = aim(rng, n)
+    target = a.astype(np.float64) + u[:, None] * ab.astype(np.float64) + v[:, None] * ac.astype(np.float64)
+    dist = scale * 10.0 ** rng.uniform(-2, 1.5, n)
+    dirn = rng.standard_normal((n, 3))
+    grazing = rng.random(n) < 0.2  # direction nearly in the triangle's plane
+    nrm = np.cross(ab.astype(np.float64), ac.astype(np.float64))
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    dirn = np.where(grazing[:, None], dirn - nrm * np.einsum("ij,ij->i", dirn, nrm)[:, None] * (1 - 1e-3 * rng.random((n, 1))), dirn)
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    o = (target - dirn * dist[:, None]).astype(F)
+    behind = rng.random(n) < 0.1
+    dirn = np.where(behind[:, None], -dirn, dirn)
+    # normalise the way vectormath.h:60-66 does: float sum of squares, double rsqrt rounded to float
+    rr = (target - o.astype(np.float64)).astype(F) * np.where(behind, F(-1), F(1))[:, None]
+    s = rr[:, 0] * rr[:, 0] + rr[:, 1] * rr[:, 1] + rr[:, 2] * rr[:, 2]
+    inv = (1.0 / np.sqrt(s.astype(np.float64))).astype(F)
+    r = rr * inv[:, None]
+    return a, ab, ac, o, r
+
+
+def aim_inside(rng, n):
+    u = rng.random(n); v = rng.random(n) * (1 - u)
+    return u, v
+
+
+def aim_edges(rng, n):
+    """On or within a few ulps of an edge or a vertex."""
+    u = rng.random(n); v = rng.random(n) * (1 - u)
+    which = rng.integers(0, 6, n)
+    tiny = (rng.standard_normal(n) * 10.0 ** rng.uniform(-9, -4, n))
+    u = np.where(which == 0, tiny, u); v = np.where(which == 1, tiny, v)
+    v = np.where(which == 2, 1 - u + tiny, v)
+    u = np.where(which == 3, tiny, u); v = np.where(which == 3, tiny, v)
+    u = np.where(which == 4, 1 + tiny, u); v = np.where(which == 4, tiny, v)
+    u = np.where(which == 5, tiny, u); v = np.where(which == 5, 1 + tiny, v)
+    return u, v
+
+
+def aim_anywhere(rng, n):
+    return rng.uniform(-2, 3, n), rng.uniform(-2, 3, n)
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.01, 50.0), (20.0, 300.0), (1e-3, 0.0), (5.0, -1000.0)])
+@pytest.mark.parametrize("aim", [aim_inside, aim_edges, aim_anywhere], ids=["inside", "edges", "anywhere"])
+def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
+    rng = np.random.default_rng(hash((scale, offset, aim.__name__)) & 0xffff)
+    n = 300000
+    a, ab, ac, o, r = make_cases(rng, n, scale, offset, aim)
+    acc, acc_uv, d, u, v, det = exact_test(a, ab, ac, o, r)
+    T = preprocess(a, ab, ac)
+    m, onorm, odr = ray_side(o, r)
+    kc = fma(T["k1"], onorm, T["k2"])
+    p1, p2, inside, sure, sd, ad = stages(T, o, r, m, kc)
+    lmax = F(T["L"].max() * 1.001)
+    e = lmax * kc
+    # 1. no slab stage rejects what the exact test accepts
+    assert not (acc & ~p1).any(), "first slab rejected an accepted hit"
+    assert not (acc & ~p2).any(), "second slab pair rejected an accepted hit"
+    # 2. "surely inside" proves the exact det, u, v tests
+    assert not (inside & ~acc_uv).any(), "surely-inside verdict on a triangle the exact test rejects"
+    # 3. distance verdicts of the nearest walk: never skip an accepted hit that is nearer than best
+    best = (np.abs(d) * rng.uniform(0.5, 1.5, n).astype(F)).astype(F)
+    behind = sure & (sd + e < 0)
+    farther = sure & (sd - e > 0) & (sd - e > best * (ad + kc) * F(1.00001))
+    assert not (behind & acc).any(), "skipped as behind the origin, but the exact test accepts"
+    assert not (farther & acc & (d < best)).any(), "skipped as farther than best, but the exact d is nearer"
+    # 4. distance verdicts of the shadow walk
+    dmax = (np.abs(d) * rng.uniform(0.5, 1.5, n).astype(F)).astype(F)
+    blocker = acc & (d > F(0.00001)) & (d < dmax)
+    out = sure & ((sd + e < F(0.0000099) * (ad - kc)) | (sd - e > dmax * (ad + kc) * F(1.00001)))
+    assert not (out & blocker).any(), "opaque triangle declared harmless, but it blocks"
+    sure_block = inside & (sd - e > F(0.0000101) * (ad + kc)) & (sd + e < dmax * (ad - kc) * F(0.99999))
+    assert not (sure_block & ~blocker).any(), "declared a blocker, but the exact test disagrees"
+    sure_transparent = inside & (sd - e > 0)
+    assert not (sure_transparent & ~acc).any(), "declared an accepted hit, but the exact test rejects (d < 0)"
+    # 5. the bounding sphere of the triangle (as k_grid_bounds builds it), widened by the visit's fuzz, is never
+    #    culled for an accepted hit; the bundle is the ray and a second direction up to 2 degrees away
+    H = batch_header(T)
+    other = (r + (rng.standard_normal((n, 3)) * 10.0 ** rng.uniform(-6, -1.5, (n, 1))).astype(F)).astype(F)
+    for axis in (r, other):
+        dlt = r - axis
+        rho = (np.sqrt(dot32(dlt, dlt)) * F(1.001) + F(1e-7)).astype(F)
+        inv_cos = batch_cos(H, axis, rho)
+        assert sphere_may_hit(H, inv_cos, r, m, odr, onorm, np.full(n, np.inf, F))[acc].all(), "sphere culled an accepted hit"
+        assert sphere_may_hit(H, inv_cos, r, m, odr, onorm, best)[acc & (d < best)].all(), "sphere culled a hit nearer than best"
+        assert sphere_may_hit(H, inv_cos, r, m, odr, onorm, dmax)[blocker].all(), "sphere culled a blocker"
+    fuzz = batch_cos(H, r, np.full(n, F(1e-7), F))
+    # the filter is not vacuous: it rejects most misses and proves most clear hits
+    if aim is aim_anywhere:
+        assert (~p1 | ~p2)[~acc].mean() > 0.5
+        assert (~sphere_may_hit(H, fuzz, r, m, odr, onorm, np.full(n, np.inf, F)))[~acc].mean() > 0.2
+    if aim is aim_inside and scale == 1.0 and offset == 0.0:  # (small triangles far from the origin leave little to prove)
+        assert inside[acc].mean() > 0.5
+
+
+def test_nan_rays_and_triangles_are_never_rejected():
+    rng = np.random.default_rng(5)
+    n = 1000
+    a, ab, ac, o, r = make_cases(rng, n, 1.0, 0.0, aim_anywhere)
+    r[::2] = np.nan
+    a[1::2, 0] = np.nan
+    T = preprocess(a, ab, ac)
+    m, onorm, odr = ray_side(o, r)
+    with np.errstate(all="ignore"):
+        kc = fma(T["k1"], onorm, T["k2"])
+        p1, p2, inside, sure, sd, ad = stages(T, o, r, m, kc)
+    assert p1.all() and p2.all() and not inside.any() and not sure.any()

@@ -1,0 +1,79 @@
+"""The walk kernels' conservative filter and batch culling change nothing but the time.
+
+Option "filter" = 0 makes every listed triangle of every visited cell take the exact Moeller-Trumbore
+test (src/intersection.c:58-86), as the reference does; the default path rejects most of them earlier
+(bounding sphere of a batch, three Pluecker slabs, distance bounds).  Both must give the same frame,
+bit for bit: ids, raw float colour and min/max.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = [
+    ("scenes/temple/temple", {}, 640, 360, False),
+    ("scenes/temple/temple", {}, 333, 187, False),
+    ("scenes/ulica/ulica", {}, 160, 120, False),        # reflections and refractions: incoherent secondary rays
+    ("scenes/pokoj/s2", {}, 200, 150, True),            # textured, transparent surfaces
+    ("scenes/s2/s2", {}, 160, 120, False),              # planar lights
+    ("scenes/s3/s3", {}, 320, 240, False),
+    ("scenes/s5/s5", {}, 160, 120, False),
+    ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 128, 96, False),
+]
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    os.chdir(ROOT)
+    r = rt.Renderer(0)
+    yield r
+    r.set_option("filter", 1)
+    r.close()
+
+
+def frame(renderer, scene, flt, count=False):
+    renderer.set_option("filter", flt)
+    renderer.set_option("count", 1 if count else 0)
+    try:
+        renderer.upload(scene)
+        renderer.frame_begin()
+        out = renderer.render_host()
+        cnt = renderer.counters().asdict() if count else None
+    finally:
+        renderer.set_option("filter", 1)
+        renderer.set_option("count", 0)
+    return out, cnt
+
+
+@pytest.mark.parametrize("prefix,over,w,h,tex", CASES, ids=[c[0].split("/")[1] + "_%dx%d" % (c[2], c[3]) for c in CASES])
+def test_filter_on_and_off_give_the_same_frame(renderer, prefix, over, w, h, tex):
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    scene = rt.Scene(os.path.join(ROOT, prefix), texture=tex, width=w, height=h, **over)
+    on, _ = frame(renderer, scene, 1)
+    off, _ = frame(renderer, scene, 0)
+    assert np.array_equal(on["ids"], off["ids"])
+    assert np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32))
+    assert np.array_equal(on["minmax"].view(np.uint32), off["minmax"].view(np.uint32))
+
+
+def test_filter_counters(renderer):
+    scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=320, height=180)
+    _, on = frame(renderer, scene, 1, count=True)
+    _, off = frame(renderer, scene, 0, count=True)
+    # the queries and the algorithmic S, T do not depend on the filter
+    for k in ("nearest_queries", "shadow_queries", "nearest_steps", "nearest_tests"):
+        assert on[k] == off[k], k
+    for f in ("nearest", "shadow"):
+        # off: nothing is culled and every executed test ends in the exact one
+        assert off[f + "_batches_culled"] == 0
+        assert off[f + "_exact"] > 0 and off[f + "_exact"] >= off[f + "_stage3"] >= on[f + "_stage3"]
+        # on: batches are culled, few tests reach the exact one, and fewer tests are executed at all
+        assert 0 < on[f + "_batches_culled"] < on[f + "_batches"]
+        assert on[f + "_exact"] * 10 < off[f + "_exact"]
+        assert on[f + "_lane_slots"] < off[f + "_lane_slots"]
+        assert on[f + "_stage2"] >= on[f + "_stage3"] >= on[f + "_exact"]
