@@ -18,8 +18,10 @@ Extra objects on the JSON line:
   roofline      the dominant kernel (shadow or nearest walk): algorithmic bytes per launch
                 (64 B per ray + 8 B per visited voxel + 40 B per listed triangle, S and T counted by the
                 kernel's own counting variant in an untimed pass) / its average launch duration from HIP
-                events on the launch stream.  The scene is cache-resident, so this logical rate can
-                exceed the HBM peak; valu_lane_ops_frac prices the same launch against fp32 VALU issue.
+                events on the launch stream.  The scene is cache-resident and most listed triangles are
+                rejected a batch at a time, so this logical rate exceeds the HBM peak by a wide margin;
+                `traffic` is what the launch really moved to and from HBM (rocprofv3 counters), and
+                walk_stats says how much of the listed work was executed.
   cpu_baseline  the unmodified reference (oracle/_ref/ref_dump) or, if that binary is absent, the C
                 oracle, single-threaded on the host, on the same scene at a reduced resolution.
 """
@@ -34,7 +36,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # HBM3E peak, GB/s
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x Hz: fp32 vector instructions (lane-ops) per second
 
 
 def cpu_baseline(prefix, over, width, height):
@@ -144,8 +145,6 @@ def main():
         per_launch = args.steps / launches  # frames per launch of this family (1 when the frame is one chunk)
         alg_bytes = (64.0 * q + 8.0 * S + 40.0 * T) * per_launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # the same launch priced against vector issue: ~30 fp32 lane-ops per listed triangle (Moeller-Trumbore, no FMA)
-        valu_frac = (30.0 * T * per_launch) / (avg_ms * 1e-3) / VALU_LANE_OPS if avg_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
@@ -167,9 +166,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_" + fam, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "valu_lane_ops_frac": round(valu_frac, 4),
-                         "note": "logical bytes (64 B/ray + 8 B/voxel + 40 B/listed triangle); the scene is cache-resident, "
-                                 "so frac can exceed 1 without touching HBM; the kernel is fp32-VALU bound"},
+                         "listed_tests_per_launch": int(T * per_launch),
+                         "executed_tests_frac": round(cnt[fam + "_lane_slots"] / T, 4) if T else None,
+                         "note": "logical bytes (64 B/ray + 8 B/voxel + 40 B/listed triangle); the scene is cache-resident and "
+                                 "batches of listed triangles are culled, so frac exceeds 1 without touching HBM; the kernel is "
+                                 "bound by instruction issue (see profiles/)"},
         }
         def ratio(a, b):
             return round(a / b, 4) if b else None

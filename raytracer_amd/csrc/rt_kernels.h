@@ -394,25 +394,38 @@ __global__ void k_preprocess(int nt, const float *__restrict__ verts, f3 ob, con
 
 // ------------------------------------------------------------------------------------------------
 // Grid build, pass 1 (voxelize.c:252-284): voxel index box of every triangle and the number of
-// references each cell will receive.  box: lo[3], hi[3] per triangle.
-__global__ void k_tri_boxes(int nt, const float *__restrict__ verts, GridP g, int *__restrict__ box,
-                            uint32_t *__restrict__ counts) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nt) return;
-  int lo[3], hi[3];
+// references each cell will receive.  box: lo[3], hi[3] per triangle, followed by the union box of every
+// group of 64 consecutive triangles (at box + 6 nt), which lets k_grid_fill skip whole groups.
+__global__ void __launch_bounds__(256) k_tri_boxes(int nt, const float *__restrict__ verts, GridP g, int *__restrict__ box,
+                                                   uint32_t *__restrict__ counts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = t < nt;
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+  if (valid) {
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    int a = f2i_x86((verts[9 * t + k] - g.dmin[k]) / g.cs[k]);
-    int b = f2i_x86((verts[9 * t + 3 + k] - g.dmin[k]) / g.cs[k]);
-    int c = f2i_x86((verts[9 * t + 6 + k] - g.dmin[k]) / g.cs[k]);
-    lo[k] = max(min3i(a, b, c), 0);            // a vertex outside the domain would index outside the
-    hi[k] = min(max3i(a, b, c), g.nv[k] - 1);  // reference's voxel array; clamp instead of faulting
-    box[6 * t + k] = lo[k];
-    box[6 * t + 3 + k] = hi[k];
+    for (int k = 0; k < 3; k++) {
+      int a = f2i_x86((verts[9 * t + k] - g.dmin[k]) / g.cs[k]);
+      int b = f2i_x86((verts[9 * t + 3 + k] - g.dmin[k]) / g.cs[k]);
+      int c = f2i_x86((verts[9 * t + 6 + k] - g.dmin[k]) / g.cs[k]);
+      lo[k] = max(min3i(a, b, c), 0);            // a vertex outside the domain would index outside the
+      hi[k] = min(max3i(a, b, c), g.nv[k] - 1);  // reference's voxel array; clamp instead of faulting
+      box[6 * t + k] = lo[k];
+      box[6 * t + 3 + k] = hi[k];
+    }
+    for (int i = lo[0]; i <= hi[0]; i++)
+      for (int j = lo[1]; j <= hi[1]; j++)
+        for (int k = lo[2]; k <= hi[2]; k++) atomicAdd(&counts[cell_index(g, i, j, k)], 1u);
   }
-  for (int i = lo[0]; i <= hi[0]; i++)
-    for (int j = lo[1]; j <= hi[1]; j++)
-      for (int k = lo[2]; k <= hi[2]; k++) atomicAdd(&counts[cell_index(g, i, j, k)], 1u);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], __shfl_xor(lo[k], off)); hi[k] = max(hi[k], __shfl_xor(hi[k], off)); }
+  }
+  if (valid && lane_id() == 0) {
+    int *gb = box + 6 * (long long)nt + 6 * (t >> 6);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gb[k] = lo[k]; gb[3 + k] = hi[k]; }
+  }
 }
 
 // Exclusive scan of the per-cell counts into cell_start[0..ncells] (one 1024-thread block).
@@ -455,26 +468,36 @@ __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *_
   const int lane = lane_id();
   int ck = cell % g.nv[2], cj = (cell / g.nv[2]) % g.nv[1], ci = cell / (g.nv[2] * g.nv[1]);
   uint32_t pos = beg;
-  for (int t0 = 0; t0 < nt && pos < end; t0 += 64) {
-    int t = t0 + lane;
-    bool in = false;
-    if (t < nt) {
-      const int *b = box + 6 * t;
-      in = ci >= b[0] && ci <= b[3] && cj >= b[1] && cj <= b[4] && ck >= b[2] && ck <= b[5];
+  const int ngroups = (nt + 63) / 64;
+  const int *gbox = box + 6 * (long long)nt;
+  for (int g0 = 0; g0 < ngroups && pos < end; g0 += 64) {
+    // which of the next 64 groups of 64 triangles can contain a triangle of this cell at all
+    bool cand = false;
+    if (g0 + lane < ngroups) {
+      const int *b = gbox + 6 * (g0 + lane);
+      cand = ci >= b[0] && ci <= b[3] && cj >= b[1] && cj <= b[4] && ck >= b[2] && ck <= b[5];
     }
-    unsigned long long m = __ballot(in);
-    if (in) {
-      uint32_t p = pos + __popcll(m & lanes_below(lane));
-      const float4 *F = reinterpret_cast<const float4 *>(g.filt + kRecFloats * (long long)t);
-      float4 *R = reinterpret_cast<float4 *>(recs + p);
+    for (unsigned long long gm = __ballot(cand); gm != 0 && pos < end; gm &= gm - 1) {
+      const int t = (g0 + __ffsll(gm) - 1) * 64 + lane;
+      bool in = false;
+      if (t < nt) {
+        const int *b = box + 6 * t;
+        in = ci >= b[0] && ci <= b[3] && cj >= b[1] && cj <= b[4] && ck >= b[2] && ck <= b[5];
+      }
+      unsigned long long m = __ballot(in);
+      if (in) {
+        uint32_t p = pos + __popcll(m & lanes_below(lane));
+        const float4 *F = reinterpret_cast<const float4 *>(g.filt + kRecFloats * (long long)t);
+        float4 *R = reinterpret_cast<float4 *>(recs + p);
 #pragma unroll
-      for (int q = 0; q < kRecVecs; q++) R[q] = F[q];
-      refs[p] = t;
-      const float4 n = F[0];  // n, k1
-      const float inv = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
-      nrm[p] = make_float4(n.x * inv, n.y * inv, n.z * inv, 0.0f);  // NaN for a degenerate triangle: its batch never culls
+        for (int q = 0; q < kRecVecs; q++) R[q] = F[q];
+        refs[p] = t;
+        const float4 n = F[0];  // n, k1
+        const float inv = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+        nrm[p] = make_float4(n.x * inv, n.y * inv, n.z * inv, 0.0f);  // NaN for a degenerate triangle: its batch never culls
+      }
+      pos += __popcll(m);
     }
-    pos += __popcll(m);
   }
 }
 // Grid build, pass 3: the header of every batch of kBatch consecutive records of a cell's list: bounding
@@ -1210,11 +1233,24 @@ __global__ void __launch_bounds__(256) k_minmax_partial(const Node *__restrict__
     for (int k = 0; k < 3; k++) { partial[blockIdx.x * 6 + k] = mn[k]; partial[blockIdx.x * 6 + 3 + k] = mx[k]; }
   }
 }
-__global__ void k_minmax_final(const float *__restrict__ partial, int nblocks, float *__restrict__ minmax) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float mn[3] = {minmax[0], minmax[1], minmax[2]}, mx[3] = {minmax[3], minmax[4], minmax[5]};
-  for (int b = 0; b < nblocks; b++) mm_fold(mn, mx, partial + 6 * b, partial + 6 * b + 3);
-  for (int k = 0; k < 3; k++) { minmax[k] = mn[k]; minmax[3 + k] = mx[k]; }
+__global__ void __launch_bounds__(256) k_minmax_final(const float *__restrict__ partial, int nblocks, float *__restrict__ minmax) {
+  __shared__ float sm[4][6];
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
+  for (int b = threadIdx.x; b < nblocks; b += 256) mm_fold(mn, mx, partial + 6 * b, partial + 6 * b + 3);
+  for (int off = 32; off > 0; off >>= 1) {
+    float omn[3], omx[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { omn[k] = __shfl_down(mn[k], off); omx[k] = __shfl_down(mx[k], off); }
+    mm_fold(mn, mx, omn, omx);
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; k++) { sm[threadIdx.x >> 6][k] = mn[k]; sm[threadIdx.x >> 6][3 + k] = mx[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float fmn[3] = {minmax[0], minmax[1], minmax[2]}, fmx[3] = {minmax[3], minmax[4], minmax[5]};  // the running range of earlier chunks
+    for (int wv = 0; wv < 4; wv++) mm_fold(fmn, fmx, sm[wv], sm[wv] + 3);
+    for (int k = 0; k < 3; k++) { minmax[k] = fmn[k]; minmax[3 + k] = fmx[k]; }
+  }
 }
 __global__ void k_minmax_init(float *minmax) {
   if (threadIdx.x < 3) minmax[threadIdx.x] = FLT_MAX;       // raytrace.c:318

@@ -334,7 +334,7 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   int rc;
   if ((rc = dev_alloc(c, &c->d_verts, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->d_geom, (size_t)s->nt * 9)) ||
       (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_filt, (size_t)s->nt * kRecFloats)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
-      (rc = dev_alloc(c, &c->d_box, (size_t)s->nt * 6)) || (rc = dev_alloc(c, &c->d_surf, (size_t)s->ns)) ||
+      (rc = dev_alloc(c, &c->d_box, (size_t)s->nt * 6 + ((size_t)s->nt + 63) / 64 * 6)) || (rc = dev_alloc(c, &c->d_surf, (size_t)s->ns)) ||
       (rc = dev_alloc(c, &c->d_lights, (size_t)s->nl)) || (rc = dev_alloc(c, &c->d_planar, (size_t)s->npl)))
     return rc;
   static_assert(sizeof(rtgpu_surface) == sizeof(SurfaceD) && sizeof(rtgpu_light) == sizeof(LightD) &&
@@ -549,7 +549,7 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
       int blocks = (n0 + 255) / 256;
       if (blocks > kPartialBlocks) blocks = kPartialBlocks;
       hipLaunchKernelGGL(k_minmax_partial, dim3(blocks), dim3(256), 0, c->stream, c->d_nodes, c->d_colors, n0, c->d_partial);
-      hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, c->stream, c->d_partial, blocks, d_minmax);
+      hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, blocks, d_minmax);
     }
     hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, c->stream, c->d_ctl, c->d_totals);
   }

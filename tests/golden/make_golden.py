@@ -45,10 +45,29 @@ NATIVE = {  # native-resolution known answers (ids + BMP digests)
 }
 
 
+# larger frames kept as id buffer + 8-bit image (the reference's own BMP pixels, top row first, R G B)
+LARGE = {
+    "ulica_384x216": ("scenes/ulica/ulica", {}, (384, 216)),   # ~3.5 minutes of reference time
+}
+
+
+def large():
+    for name, (prefix, over, (w, h)) in LARGE.items():
+        r = O.run_reference(os.path.join(ROOT, prefix), width=w, height=h, cwd=os.path.join(ROOT, "scenes"), want_bmp=True)
+        bmp = r["bmp"]
+        img = np.frombuffer(bmp[54:], np.uint8).reshape(h, (w * 3 + 3) // 4 * 4)[:, :w * 3][::-1].reshape(h, w, 3)[:, :, ::-1]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), ids=r["ids"], img=np.ascontiguousarray(img), minmax=r["minmax"],
+                            gamma=np.float32(r["gamma"]), bmp_sha256=hashlib.sha256(bmp).hexdigest(), prefix=prefix,
+                            seconds=r["seconds"])
+        print(name, r["ids"].shape, "hits", int((r["ids"] >= 0).sum()), "%.2fs" % r["seconds"], hashlib.sha256(bmp).hexdigest())
+
+
 def main():
     os.chdir(ROOT)
     if not O.have_reference():
         sys.exit("build oracle/_ref first: make -C oracle ref")
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        return large()
     for name, (prefix, over, (w, h), tex) in CASES.items():
         cwd = ROOT if tex else os.path.join(ROOT, "scenes")  # scenes/ has no textures/ directory
         over_abs = {k: os.path.join(ROOT, v) for k, v in over.items()}
