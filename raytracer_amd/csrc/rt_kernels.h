@@ -564,6 +564,30 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restri
     }
   }
 }
+// One bit per cell: does it list any triangle?  The walk kernels keep this map in LDS (kOccWords words, grids
+// up to 49 152 cells) so that stepping through empty cells, most of a shadow ray's way to a distant light,
+// costs an LDS read instead of a trip to L2 per step.
+__global__ void k_occupancy(int ncells, const uint32_t *__restrict__ counts, uint32_t *__restrict__ occ) {
+  const int wd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (wd * 32 >= ncells) return;
+  uint32_t bits = 0;
+  for (int b = 0; b < 32 && wd * 32 + b < ncells; b++) bits |= (counts[wd * 32 + b] > 0u ? 1u : 0u) << b;
+  occ[wd] = bits;
+}
+constexpr int kOccWords = 1536;
+// Copies the occupancy map into the block's LDS if it fits; returns whether it did.
+RT_D bool load_occupancy(const GridP &g, uint32_t *occ_s) {
+  const bool fits = g.ncells <= kOccWords * 32;
+  if (fits)
+    for (int i = threadIdx.x; i * 32 < g.ncells; i += blockDim.x) occ_s[i] = g.occ[i];
+  __syncthreads();
+  return fits;
+}
+RT_D bool cell_occupied(const GridP &g, const uint32_t *occ_s, bool in_lds, int cell) {
+  const uint32_t wd = in_lds ? occ_s[cell >> 5] : g.occ[cell >> 5];
+  return (wd >> (cell & 31)) & 1u;
+}
+
 // Batches per cell, the input of the scan that gives hdr_start.
 __global__ void k_batch_counts(int ncells, const uint32_t *__restrict__ counts, uint32_t *__restrict__ nb) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -616,7 +640,9 @@ template <bool COUNT>
 __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
                                                  Ctl *__restrict__ ctl, int level) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
+  __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
+  const bool occ_in_lds = load_occupancy(g, occ_s);
   const int lane = lane_id();
   const int nrays = ctl->count[level];
   const uint32_t *__restrict__ cstart = g.cell_start;
@@ -651,9 +677,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       // stand on the first non-empty cell of the walk (the start voxel counts as visited)
       for (;;) {
         mycell = cell_index(g, w.i, w.j, w.k);
-        mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-        if (COUNT) { nS++; nT += mycnt; }
-        if (mycnt > 0) break;
+        if (COUNT) nS++;
+        if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
+          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+          if (COUNT) nT += mycnt;
+          break;
+        }
         dda_step(w);
         if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
       }
@@ -758,9 +787,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
             dda_step(w);
             if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
             mycell = cell_index(g, w.i, w.j, w.k);
-            mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-            if (COUNT) { nS++; nT += mycnt; }
-            if (mycnt > 0) break;
+            if (COUNT) nS++;
+            if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
+              mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+              if (COUNT) nT += mycnt;
+              break;
+            }
           }
         }
       }
@@ -924,7 +956,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
                                                 Ctl *__restrict__ ctl, int level, int node_base) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
+  __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
+  const bool occ_in_lds = load_occupancy(g, occ_s);
   const int lane = lane_id();
   const int n = ctl->count[level];
   const long long total = (long long)n * sp.nslots;
@@ -974,9 +1008,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
             if (COUNT) nW++;
             for (;;) {
               mycell = cell_index(g, w.i, w.j, w.k);
-              mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-              if (COUNT) { nS++; nT += mycnt; }
-              if (mycnt > 0) break;
+              if (COUNT) nS++;
+              if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
+                mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+                if (COUNT) nT += mycnt;
+                break;
+              }
               dda_step(w);
               if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
             }
@@ -1096,9 +1133,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
           dda_step(w);
           if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
           mycell = cell_index(g, w.i, w.j, w.k);
-          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-          if (COUNT) { nS++; nT += mycnt; }
-          if (mycnt > 0) break;
+          if (COUNT) nS++;
+          if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
+            mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+            if (COUNT) nT += mycnt;
+            break;
+          }
         }
       }
     }

@@ -60,6 +60,7 @@ struct GridP {
   int32_t nv[3];
   int32_t ncells;
   const uint32_t *cell_start;  // ncells+1 offsets into cell_tris
+  const uint32_t *occ;         // one bit per cell: 1 = its list is not empty
   const TriRec *cell_tris;
   const uint32_t *hdr_start;   // ncells+1 offsets into cell_hdrs (one header per kBatch records of a cell)
   const BatchHdr *cell_hdrs;

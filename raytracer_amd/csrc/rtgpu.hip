@@ -49,7 +49,7 @@ struct rtgpu_ctx {
   SurfaceD *d_surf = nullptr;
   LightD *d_lights = nullptr;
   PlanarD *d_planar = nullptr;
-  uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr, *d_hdr_start = nullptr;
+  uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr, *d_hdr_start = nullptr, *d_occ = nullptr;
   BatchHdr *d_hdrs = nullptr;
   float4 *d_nrm = nullptr;
   size_t cap_hdrs = 0;
@@ -251,7 +251,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs);
-  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
+  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->d_rank); dev_free(&c->d_ctl); dev_free(&c->d_totals);
@@ -393,12 +393,13 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   int rc;
   if ((size_t)ncells + 1 > c->cap_cells) {
     if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1)) ||
-        (rc = dev_alloc(c, &c->d_nbatch, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_hdr_start, (size_t)ncells + 1))) return rc;
+        (rc = dev_alloc(c, &c->d_nbatch, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_hdr_start, (size_t)ncells + 1)) ||
+        (rc = dev_alloc(c, &c->d_occ, (size_t)ncells / 32 + 1))) return rc;
     c->cap_cells = (size_t)ncells + 1;
   }
   GridP g;
   for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
-  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.cell_hdrs = nullptr; g.cell_nrm = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
+  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.occ = c->d_occ; g.cell_hdrs = nullptr; g.cell_nrm = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
     Span sp(c, W_PRE);
@@ -436,6 +437,7 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     g.cell_hdrs = c->d_hdrs;
     g.cell_nrm = reinterpret_cast<const float *>(c->d_nrm);
     hipLaunchKernelGGL(k_batch_counts, dim3((ncells + 255) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_nbatch);
+    hipLaunchKernelGGL(k_occupancy, dim3((ncells / 32 + 256) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_occ);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_nbatch, c->d_hdr_start);
     hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs, c->d_refs, c->d_nrm);
     hipLaunchKernelGGL(k_grid_bounds, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, g, c->d_hdrs);
