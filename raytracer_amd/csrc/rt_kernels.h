@@ -889,11 +889,26 @@ __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__re
   if (valid) nodes[node_base + idx] = nd;
 }
 
-// Exclusive prefix count of primary hits in row-major pixel order, used to replay the order in which
-// the reference consumes rand() for planar lights (raytrace.c:245-251): the shaded hit of pixel p
-// uses the 32*npl values starting at 32*npl*rank(p).  Single 1024-thread block over the image.
-__global__ void __launch_bounds__(1024) k_hit_rank(int w, int h, int tiles_x, const Node *__restrict__ nodes,
-                                                   int32_t *__restrict__ rank) {
+// Replay of the order in which the reference consumes rand() for planar lights (raytrace.c:245-251).
+// rtRayTrace shades a hit after it has traced the hit's reflected and then its refracted ray
+// (raytrace.c:192-204 before :241), pixels in row-major order: the hits of a frame draw their
+// 32*npl values in post-order of each pixel's ray tree, trees in pixel order.  The shaded hit with
+// rank k uses the values starting at 32*npl*k.  Three passes over the node arrays:
+//   k_subtree_hits   deepest level first: shaded hits in the subtree of every node
+//   k_tree_starts    exclusive prefix of the primary nodes' subtree sizes in pixel order (one block)
+//   k_assign_ranks   top level first: start of each child's subtree, then the node's own rank
+__global__ void __launch_bounds__(256) k_subtree_hits(const Node *__restrict__ nodes, int32_t *__restrict__ size,
+                                                      const Ctl *__restrict__ ctl, int level, int node_base) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ctl->count[level]) return;
+  const Node v = nodes[node_base + idx];
+  int32_t s = v.tri >= 0 ? 1 : 0;
+  if (v.refl >= 0) s += size[v.refl];
+  if (v.refr >= 0) s += size[v.refr];
+  size[node_base + idx] = s;
+}
+__global__ void __launch_bounds__(1024) k_tree_starts(int w, int h, int tiles_x, const int32_t *__restrict__ size,
+                                                      int32_t *__restrict__ rank) {
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -907,7 +922,7 @@ __global__ void __launch_bounds__(1024) k_hit_rank(int w, int h, int tiles_x, co
     if (p < n) {
       int x = p % w, y = p / w;
       node = ((y >> 3) * tiles_x + (x >> 3)) * kTilePixels + (y & 7) * kTile + (x & 7);
-      v = nodes[node].tri >= 0 ? 1u : 0u;
+      v = (uint32_t)size[node];
     }
     uint32_t x = v;
 #pragma unroll
@@ -924,6 +939,19 @@ __global__ void __launch_bounds__(1024) k_hit_rank(int w, int h, int tiles_x, co
     if (tid == 1023) carry_s = prefix + x;
     __syncthreads();
   }
+}
+__global__ void __launch_bounds__(256) k_assign_ranks(const Node *__restrict__ nodes, const int32_t *__restrict__ size,
+                                                      int32_t *__restrict__ rank, const Ctl *__restrict__ ctl, int level,
+                                                      int node_base) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ctl->count[level]) return;
+  const int gidx = node_base + idx;
+  const Node v = nodes[gidx];
+  const int32_t start = rank[gidx];  // set by k_tree_starts (level 0) or by the parent
+  const int32_t a = v.refl >= 0 ? size[v.refl] : 0, b = v.refr >= 0 ? size[v.refr] : 0;
+  if (v.refl >= 0) rank[v.refl] = start;
+  if (v.refr >= 0) rank[v.refr] = start + a;
+  rank[gidx] = start + a + b;
 }
 
 // Position of shadow-query slot `slot` of a shaded hit: a point light, or sample d of planar light c
@@ -990,7 +1018,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         have_result = true;
         a = ld3(nd.p);
         f3 b, lcol; float lflux;
-        slot_light(sp, slot, rand_rank ? rand_rank[nidx] : 0, b, lflux, lcol);
+        slot_light(sp, slot, rand_rank ? rand_rank[node_base + nidx] : 0, b, lflux, lcol);
         r = ray3(a, b);
         const float kt_cur = sp.surf[sp.tri_sid[current]].kt;
         bool lit_walk = true;
@@ -1221,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
         const float t = ts[slot];
         if (t >= 0.0f) {
           f3 lp, lcol; float lflux;
-          slot_light(sp, slot, rand_rank[idx], lp, lflux, lcol);
+          slot_light(sp, slot, rand_rank[gidx], lp, lflux, lcol);
           sum = light_term(sf, norm, r, ray3(onew, lp), onew, lp, lflux, lcol, nc, t, sp.distmod);
         }
         sum = mul3(sum, 1.0f / kPlanarSamples);

@@ -70,7 +70,7 @@ struct rtgpu_ctx {
   Hit *d_hits = nullptr;  // sized for the largest level
   Node *d_nodes = nullptr;
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
-  int32_t *d_rank = nullptr;
+  int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
   Ctl *d_ctl = nullptr;
   unsigned long long *d_totals = nullptr;  // [kStatCount + kMaxLevels + 1]
   // timing
@@ -181,8 +181,22 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
   if ((rc = dev_alloc(c, &c->d_nodes, total))) return rc;
   if ((rc = dev_alloc(c, &c->d_colors, total * 4))) return rc;
   if ((rc = dev_alloc(c, &c->d_ts, total * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)))) return rc;
-  if ((rc = dev_alloc(c, &c->d_rank, c->cap[0]))) return rc;
+  const size_t nrank = c->npl > 0 ? total : 1;
+  if ((rc = dev_alloc(c, &c->d_rank, nrank)) || (rc = dev_alloc(c, &c->d_size, nrank))) return rc;
   c->chunk_tiles_cap = tiles;
+  return RTGPU_OK;
+}
+
+// The glibc rand() stream from seed 1, at least `need` values, on the device.
+int ensure_rand(rtgpu_ctx *c, size_t need) {
+  if (need <= c->cap_rand) return RTGPU_OK;
+  std::vector<int32_t> tab;
+  glibc_rand_stream(tab, need);
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_rand, need))) return rc;
+  HIPCHK(c, hipMemcpy(c->d_rand, tab.data(), need * sizeof(int32_t), hipMemcpyHostToDevice));
+  c->cap_rand = need;
+  c->shade.rand_tab = c->d_rand;
   return RTGPU_OK;
 }
 
@@ -254,7 +268,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
-  dev_free(&c->d_rank); dev_free(&c->d_ctl); dev_free(&c->d_totals);
+  dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_ctl); dev_free(&c->d_totals);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -328,9 +342,6 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   }
   c->levels = c->fan > 0 ? kMaxLevels : 1;
   c->chunk_tiles_cap = 0;
-  if (c->npl > 0 && c->fan > 0)
-    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights together with reflective/transparent surfaces: the rand() replay "
-                                         "order of secondary hits is not implemented");
   int rc;
   if ((rc = dev_alloc(c, &c->d_verts, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->d_geom, (size_t)s->nt * 9)) ||
       (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_filt, (size_t)s->nt * kRecFloats)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
@@ -447,19 +458,10 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   for (int k = 0; k < 3; k++) { c->ginfo.nv[k] = nv[k]; c->ginfo.cell[k] = cs[k]; c->ginfo.dmin[k] = dmin[k]; c->ginfo.dmax[k] = dmax[k]; }
   c->ginfo.ncells = ncells; c->ginfo.nrefs = (int32_t)nrefs; c->ginfo.total_flux = total_flux;
   // planar lights: the reference draws 2 rand() values per sample, 16 samples per light, per shaded hit
-  if (c->npl > 0) {
-    size_t need = (size_t)cam->sw * cam->sh * c->npl * kPlanarSamples * 2;
-    if (need > c->cap_rand) {
-      std::vector<int32_t> tab;
-      glibc_rand_stream(tab, need);
-      if ((rc = dev_alloc(c, &c->d_rand, need))) return rc;
-      HIPCHK(c, hipMemcpy(c->d_rand, tab.data(), need * sizeof(int32_t), hipMemcpyHostToDevice));
-      c->cap_rand = need;
-    }
-  }
+  if (c->npl > 0 && (rc = ensure_rand(c, (size_t)cam->sw * cam->sh * c->npl * kPlanarSamples * 2))) return rc;
   ShadeP sp;
   sp.surf = c->d_surf; sp.lights = c->d_lights; sp.planar = c->d_planar; sp.tri_aux = c->d_aux; sp.tri_sid = c->d_sid;
-  sp.rand_tab = c->npl > 0 ? c->d_rand : nullptr;
+  sp.rand_tab = c->npl > 0 ? c->d_rand : nullptr;  // (ensure_rand keeps c->shade.rand_tab current when the table grows)
   sp.nl = c->nl; sp.npl = c->npl; sp.nslots = c->nl + kPlanarSamples * c->npl;
   for (int q = 0; q < 4; q++) sp.tex_tri[q] = c->tex_tri[q];
   sp.total_flux = total_flux; sp.distmod = c->distmod;
@@ -528,8 +530,26 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
                            spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn);
       }
     }
-    if (c->npl > 0)
-      hipLaunchKernelGGL(k_hit_rank, dim3(1), dim3(1024), 0, c->stream, c->cam.sw, c->cam.sh, (int)tx, c->d_nodes, c->d_rank);
+    if (c->npl > 0) {
+      // rand() replay order of the shaded hits (one chunk = the whole image, checked above)
+      for (int L = c->levels - 1; L >= 0; L--) {
+        const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+        hipLaunchKernelGGL(k_subtree_hits, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_ctl, L, (int)c->base[L]);
+      }
+      hipLaunchKernelGGL(k_tree_starts, dim3(1), dim3(1024), 0, c->stream, c->cam.sw, c->cam.sh, (int)tx, c->d_size, c->d_rank);
+      for (int L = 0; L < c->levels; L++) {
+        const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+        hipLaunchKernelGGL(k_assign_ranks, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_rank, c->d_ctl, L, (int)c->base[L]);
+      }
+      if (c->fan > 0) {
+        // secondary hits draw random numbers too: the table must cover every shaded hit of the frame (a host sync,
+        // only for planar lights together with reflective or transparent surfaces)
+        unsigned long long shaded = 0;
+        HIPCHK(c, hipMemcpyAsync(&shaded, &c->d_ctl->stat[kShaded], sizeof shaded, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = ensure_rand(c, (size_t)shaded * c->npl * kPlanarSamples * 2))) return rc;
+      }
+    }
     if (c->shade.nslots > 0) {
       for (int L = 0; L < c->levels; L++) {
         Span sp(c, W_SHADOW);

@@ -32,6 +32,8 @@ CASES = {
     "pokoj_kafelki": ("scenes/pokoj/s2", {"cfg": "scenes/kafelki.cfg"}, (96, 72), True),
     "temple": ("scenes/temple/temple", {}, (160, 120), False),
     "ulica": ("scenes/ulica/ulica", {}, (48, 64), False),
+    # planar light of s2 with pokoj's surfaces (kt > 0 and kr > 0): rand() is also drawn at secondary hits
+    "s2_glass": ("scenes/s2/s2", {"atr": "scenes/pokoj/s2.atr"}, (120, 90), False),
 }
 
 NATIVE = {  # native-resolution known answers (ids + BMP digests)
@@ -68,7 +70,10 @@ def main():
         sys.exit("build oracle/_ref first: make -C oracle ref")
     if len(sys.argv) > 1 and sys.argv[1] == "large":
         return large()
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "only" else None   # make_golden.py only <case> ...
     for name, (prefix, over, (w, h), tex) in CASES.items():
+        if only is not None and name not in only:
+            continue
         cwd = ROOT if tex else os.path.join(ROOT, "scenes")  # scenes/ has no textures/ directory
         over_abs = {k: os.path.join(ROOT, v) for k, v in over.items()}
         r = O.run_reference(os.path.join(ROOT, prefix), width=w, height=h, cwd=cwd, want_bmp=True, **over_abs)
@@ -76,6 +81,8 @@ def main():
                             gamma=np.float32(r["gamma"]), bmp_sha256=hashlib.sha256(r["bmp"]).hexdigest(),
                             prefix=prefix, overrides=json.dumps(over), texture=tex, seconds=r["seconds"])
         print(name, r["ids"].shape, "hits", int((r["ids"] >= 0).sum()), "%.2fs" % r["seconds"])
+    if only is not None:
+        return
     known = {}
     for name, (prefix, over) in NATIVE.items():
         over_abs = {k: os.path.join(ROOT, v) for k, v in over.items()}

@@ -21,6 +21,7 @@ CASES = [
     ("scenes/ulica/ulica", {}, 160, 120, False),        # reflections and refractions: incoherent secondary rays
     ("scenes/pokoj/s2", {}, 200, 150, True),            # textured, transparent surfaces
     ("scenes/s2/s2", {}, 160, 120, False),              # planar lights
+    ("scenes/s2/s2", {"atr": "scenes/pokoj/s2.atr"}, 120, 90, False),   # planar light and secondary rays
     ("scenes/s3/s3", {}, 320, 240, False),
     ("scenes/s5/s5", {}, 160, 120, False),
     ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 128, 96, False),
@@ -50,7 +51,7 @@ def frame(renderer, scene, flt, count=False):
     return out, cnt
 
 
-@pytest.mark.parametrize("prefix,over,w,h,tex", CASES, ids=[c[0].split("/")[1] + "_%dx%d" % (c[2], c[3]) for c in CASES])
+@pytest.mark.parametrize("prefix,over,w,h,tex", CASES, ids=[c[0].split("/")[1] + ("_glass" if c[1] and "pokoj" in str(c[1]) else "") + "_%dx%d" % (c[2], c[3]) for c in CASES])
 def test_filter_on_and_off_give_the_same_frame(renderer, prefix, over, w, h, tex):
     over = {k: os.path.join(ROOT, v) for k, v in over.items()}
     scene = rt.Scene(os.path.join(ROOT, prefix), texture=tex, width=w, height=h, **over)

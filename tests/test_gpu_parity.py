@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-CASES = ["test", "s2", "s3", "s5", "pokoj", "pokoj_cegly", "pokoj_kafelki", "temple", "ulica"]
+CASES = ["test", "s2", "s2_glass", "s3", "s5", "pokoj", "pokoj_cegly", "pokoj_kafelki", "temple", "ulica"]
 
 
 @pytest.fixture(scope="module")
