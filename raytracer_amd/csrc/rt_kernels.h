@@ -142,24 +142,28 @@ RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t coun
 // (batch maxima of ga, gb from k_grid_bounds; tv = |o - c| + radius >= |o - i| for every triangle of the batch).
 // The radius grows by that much.  It comes inflated by 0.1% + 1e-5 |c| from k_grid_bounds and 1e-5 |o| is
 // added here for the rounding of these few operations.  A NaN compares false: not culled.
-RT_D bool sphere_may_hit(const float *H, float slack, f3 r, f3 m, float odr, float onorm, float tmax_opaque,
-                         bool transparent_counts_anywhere) {
-  const v4f h0 = *reinterpret_cast<const v4f *>(H);       // c, radius
-  const v4f h1 = *reinterpret_cast<const v4f *>(H + 4);   // k1, k2, transparent, inv_cos
-  const v2f h2 = *reinterpret_cast<const v2f *>(H + 8);   // ga, gb
-  const f3 c = mk3(h0.x, h0.y, h0.z);
+RT_D bool sphere_test(f3 c, float radius, bool transparent, float inv_cos, float ga, float gb, float slack, f3 r, f3 m,
+                      float odr, float onorm, float tmax_opaque, bool transparent_counts_anywhere) {
   const float ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
   const float ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
   const float ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
   const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
   const float tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
-  const float R0 = __builtin_fmaf(0.00001f, onorm, h0.w);
+  const float R0 = __builtin_fmaf(0.00001f, onorm, radius);
   const float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(tc, tc, d2)), 1.001f, R0);  // |o - c|^2 = d2 + tc^2
-  const float R = __builtin_fmaf(__builtin_fmaf(h2.y, tv, h2.x), h1.w, R0) + slack;
+  const float R = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, R0) + slack;
   // shadow walk: a transparent triangle attenuates wherever it is hit (d >= 0); an opaque one matters only before tmax_opaque
-  const float tmax = (transparent_counts_anywhere & (h1.z != 0.0f)) ? INFINITY : tmax_opaque;
+  const float tmax = (transparent_counts_anywhere & transparent) ? INFINITY : tmax_opaque;
   const bool out = (d2 > R * R * 1.00001f) | (tc + R < 0.0f) | (tc - R > tmax);
   return !out;
+}
+RT_D bool sphere_may_hit(const float *H, float slack, f3 r, f3 m, float odr, float onorm, float tmax_opaque,
+                         bool transparent_counts_anywhere) {
+  const v4f h0 = *reinterpret_cast<const v4f *>(H);       // c, radius
+  const v4f h1 = *reinterpret_cast<const v4f *>(H + 4);   // k1, k2, transparent, inv_cos
+  const v2f h2 = *reinterpret_cast<const v2f *>(H + 8);   // ga, gb
+  return sphere_test(mk3(h0.x, h0.y, h0.z), h0.w, h1.z != 0.0f, h1.w, h2.x, h2.y, slack, r, m, odr, onorm, tmax_opaque,
+                     transparent_counts_anywhere);
 }
 
 RT_D void stage_batch(const TriRec *__restrict__ recs, uint32_t c0, int n, float *rs, int lane) {
@@ -179,7 +183,7 @@ RT_D void wait_staged() {
 }
 
 // Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
-// batch cull(header) decides, for the whole wavefront, whether any of its rays can
+// batch cull(centre, radius, transparent, inv_cos, ga, gb) decides, for the whole wavefront, whether any of its rays can
 // meet the batch's bounding sphere; only then are the batch's records staged and tested:
 //   batch(k1, k2)      once per surviving batch, with the batch's filter constants
 //   pass1(record)      the side-effect-free first stage of the test (true = this lane cannot reject the
@@ -187,9 +191,9 @@ RT_D void wait_staged() {
 //                      lane for some of them does the wavefront leave the straight-line path and run
 //   f(record, index)   the full test on those records, in list order, checking
 //   more()             (wave-uniform) after each: false = stop.
-template <typename C, typename B, typename P, typename F, typename G>
+template <typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
-                      C &&cull, B &&batch, P &&pass1, F &&f, G &&more) {
+                      C &&cull, T &&tally, B &&batch, P &&pass1, F &&f, G &&more) {
   float *hs = slice;                             // kHdrChunk headers
   float *rs = slice + kHdrChunk * kHdrFloats;    // kBatch records
   const TriRec *__restrict__ recs = g.cell_tris;
@@ -208,8 +212,12 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
       batch_cos(g.cell_nrm, beg + first, count, hs, lane, bundle, f0);
     }
     for (int b = 0; b < nh; ++b) {
-      const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);
-      if (!cull(hs + b * kHdrFloats)) continue;
+      const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, radius
+      const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);   // k1, k2, transparent, inv_cos
+      const v2f h2 = *reinterpret_cast<const v2f *>(hs + b * kHdrFloats + 8);  // ga, gb
+      const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, k.z != 0.0f, k.w, h2.x, h2.y);
+      tally(1, keep ? 0 : 1);
+      if (!keep) continue;
       const uint32_t c0 = beg + (h0 + (uint32_t)b) * kBatch;
       const int n = (int)(beg + cnt - c0 < (uint32_t)kBatch ? beg + cnt - c0 : (uint32_t)kBatch);
       stage_batch(recs, c0, n, rs, lane);
@@ -460,7 +468,7 @@ __global__ void __launch_bounds__(1024) k_scan_cells(int n, const uint32_t *__re
 // appends those whose voxel box contains the cell; ballot + prefix count keeps the list in ascending
 // triangle order, which is the reference's insertion order and therefore its tie-break.
 __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *__restrict__ box, TriRec *__restrict__ recs,
-                                                   int32_t *__restrict__ refs, float4 *__restrict__ nrm) {
+                                                   int32_t *__restrict__ refs) {
   int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cell >= g.ncells) return;
   uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
@@ -492,15 +500,98 @@ __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *_
 #pragma unroll
         for (int q = 0; q < kRecVecs; q++) R[q] = F[q];
         refs[p] = t;
-        const float4 n = F[0];  // n, k1
-        const float inv = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
-        nrm[p] = make_float4(n.x * inv, n.y * inv, n.z * inv, 0.0f);  // NaN for a degenerate triangle: its batch never culls
       }
       pos += __popcll(m);
     }
   }
 }
-// Grid build, pass 3: the header of every batch of kBatch consecutive records of a cell's list: bounding
+// Grid build, pass 3: the walk order of every cell's list.  The reference's result does not depend on the
+// order a list is walked in, except that equal distances go to the smaller triangle index (the nearest walk
+// compares indices for that) and that the transparency product of a shadow ray is taken in list order.
+// Lists of 33..4096 opaque triangles are therefore re-ordered along a Morton curve of the triangles'
+// centroids inside the cell (triangles larger than half a cell first), so that the 16 records of a batch
+// lie close together and their bounding sphere is small; all other lists keep the ascending order.
+// One block per cell; 64-bit keys (class, Morton code, position) sorted with a bitonic network in LDS.
+// Also writes the unit normals of the final order.
+constexpr int kSortMax = 4096;
+RT_D uint32_t morton10(uint32_t x) {
+  x &= 0x3ffu;
+  x = (x | (x << 16)) & 0x30000ffu;
+  x = (x | (x << 8)) & 0x300f00fu;
+  x = (x | (x << 4)) & 0x30c30c3u;
+  x = (x | (x << 2)) & 0x9249249u;
+  return x;
+}
+__global__ void __launch_bounds__(256) k_grid_sort(GridP g, const TriRec *__restrict__ src, TriRec *__restrict__ dst,
+                                                   float4 *__restrict__ nrm) {
+  __shared__ unsigned long long keys[kSortMax];
+  __shared__ int transparent_s;
+  const int cell = blockIdx.x;
+  const uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
+  const int cnt = (int)(end - beg), tid = threadIdx.x;
+  if (cnt == 0) return;
+  bool sorted = cnt > 32 && cnt <= kSortMax;
+  if (sorted) {
+    if (tid == 0) transparent_s = 0;
+    __syncthreads();
+    int any = 0;
+    for (int j = tid; j < cnt; j += 256) any |= src[beg + j].kt > 0.0f ? 1 : 0;
+    if (any) atomicOr(&transparent_s, 1);
+    __syncthreads();
+    sorted = transparent_s == 0;
+  }
+  if (sorted) {
+    int n2 = 64;
+    while (n2 < cnt) n2 <<= 1;
+    const int ck = cell % g.nv[2], cj = (cell / g.nv[2]) % g.nv[1], ci = cell / (g.nv[2] * g.nv[1]);
+    const float lo[3] = {g.dmin[0] + ci * g.cs[0], g.dmin[1] + cj * g.cs[1], g.dmin[2] + ck * g.cs[2]};
+    const float big = 0.5f * fmaxf(g.cs[0], fmaxf(g.cs[1], g.cs[2]));
+    for (int j = tid; j < n2; j += 256) {
+      unsigned long long key = ~0ull;
+      if (j < cnt) {
+        const float *G = g.geom + 9 * (long long)src[beg + j].id;
+        uint32_t code = 0;
+        float extent = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const float a = G[q], b = G[q] + G[3 + q], c = G[q] + G[6 + q];
+          extent = fmaxf(extent, fmaxf(a, fmaxf(b, c)) - fminf(a, fminf(b, c)));
+          const float rel = ((a + b + c) * (1.0f / 3.0f) - lo[q]) / g.cs[q];
+          const uint32_t u = (uint32_t)fminf(fmaxf(rel * 1024.0f, 0.0f), 1023.0f);  // NaN -> 0: any order is a valid order
+          code |= morton10(u) << (2 - q);
+        }
+        key = ((unsigned long long)((extent > big ? 0u : 1u) << 30 | code) << 32) | (unsigned)j;
+      }
+      keys[j] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+      for (int jj = k >> 1; jj > 0; jj >>= 1) {
+        for (int i = tid; i < n2; i += 256) {
+          const int l = i ^ jj;
+          if (l > i) {
+            const unsigned long long x = keys[i], y = keys[l];
+            const bool up = (i & k) == 0;
+            if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (int j = tid; j < cnt; j += 256) {
+    const int from = sorted ? (int)(keys[j] & 0xffffffffull) : j;
+    const float4 *S = reinterpret_cast<const float4 *>(src + beg + from);
+    float4 *D = reinterpret_cast<float4 *>(dst + beg + j);
+#pragma unroll
+    for (int q = 0; q < kRecVecs; q++) D[q] = S[q];
+    const float4 n = S[0];  // n, k1
+    const float inv = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+    nrm[beg + j] = make_float4(n.x * inv, n.y * inv, n.z * inv, 0.0f);  // NaN for a degenerate triangle: its batch never culls
+  }
+}
+
+// Grid build, pass 4: the header of every batch of kBatch consecutive records of a cell's list: bounding
 // sphere of the batch's triangles (vertices i, i+ij, i+ik as the exact test sees them), maxima of the
 // records' error constants, transparency flag.  One wavefront per cell, 64 / kBatch batches at a time.
 __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restrict__ hdrs) {
@@ -678,13 +769,13 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       for (;;) {
         mycell = cell_index(g, w.i, w.j, w.k);
         if (COUNT) nS++;
-        if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
-          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-          if (COUNT) nT += mycnt;
-          break;
-        }
+        if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
         dda_step(w);
         if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
+      }
+      if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
+        mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+        if (COUNT) nT += mycnt;
       }
     }
     for (;;) {
@@ -717,7 +808,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
           if (ex) {
             const int id = rec_id(R);
             float d, u, v;
-            if (exact_test(g, id, to, tr, d, u, v) && id != cur && d < b) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
+            // the reference keeps the first of equal distances in its ascending list = the smallest triangle index; written
+            // on the index, the choice does not depend on the order the list is walked in (bid = -1: the voxel's exit distance)
+            if (exact_test(g, id, to, tr, d, u, v) && id != cur && (d < b || (d == b && id < bid))) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
           }
         }
       };
@@ -727,11 +820,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
         stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(proc, r, leader),
-                    [&](const float *H) {
-                      const bool hit = wave_any(proc & sphere_may_hit(H, g.slack, r, pm, odr, onorm, best, false));
-                      if (COUNT) { nBatch++; nCull += !hit; }
-                      return hit;
+                    [&](f3 c, float radius, bool transparent, float inv_cos, float ga, float gb) {
+                      return wave_any(proc & sphere_test(c, radius, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, best, false));
                     },
+                    [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
                     [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                     [&](const float *R) {
                       if (COUNT) { nWave++; if (proc) nLane++; }
@@ -768,13 +860,13 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
             test(R, lo, lr, lm, __builtin_fmaf(R[3], lon, R[11]) + g.slack, lcur, cb, cid, cu, cv, t, cpos);  // ascending t: earliest wins in a lane
           }
         }
-        // smallest d, ties to the earliest list position: the reference's strict `d < dmin` scan order
+        // smallest d, ties to the smallest triangle index: the reference's strict `d < dmin` scan of its ascending list
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
           const float od = __shfl_xor(cb, off), ou = __shfl_xor(cu, off), ov = __shfl_xor(cv, off);
           const uint32_t op = __shfl_xor(cpos, off);
           const int oi = __shfl_xor(cid, off);
-          if (od < cb || (od == cb && op < cpos)) { cb = od; cpos = op; cid = oi; cu = ou; cv = ov; }
+          if (od < cb || (od == cb && oi >= 0 && (cid < 0 || oi < cid))) { cb = od; cpos = op; cid = oi; cu = ou; cv = ov; }
         }
         if (proc) { best = cb; best_id = cid; best_u = cu; best_v = cv; }
       }
@@ -788,12 +880,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
             if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
             mycell = cell_index(g, w.i, w.j, w.k);
             if (COUNT) nS++;
-            if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
-              mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-              if (COUNT) nT += mycnt;
-              break;
-            }
+            if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
           }
+        }
+        if (alive) {
+          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+          if (COUNT) nT += mycnt;
         }
       }
     }
@@ -1037,17 +1129,17 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
             for (;;) {
               mycell = cell_index(g, w.i, w.j, w.k);
               if (COUNT) nS++;
-              if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
-                mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-                if (COUNT) nT += mycnt;
-                break;
-              }
+              if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
               dda_step(w);
               if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
             }
           }
         }
       }
+    }
+    if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
+      mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+      if (COUNT) nT += mycnt;
     }
     for (;;) {
       const unsigned long long m = __ballot(alive);
@@ -1093,11 +1185,11 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
           stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(in_group, r, leader),
-                      [&](const float *H) {
-                        const bool hit = wave_any(in_group & (result >= 0.0f) & sphere_may_hit(H, g.slack, r, pm, odr, onorm, dmax, true));
-                        if (COUNT) { nBatch++; nCull += !hit; }
-                        return hit;
+                      [&](f3 c, float radius, bool transparent, float inv_cos, float ga, float gb) {
+                        return wave_any(in_group & (result >= 0.0f) &
+                                        sphere_test(c, radius, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, dmax, true));
                       },
+                      [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
                       [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                       [&](const float *R) {
                         if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
@@ -1162,11 +1254,11 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
           if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
           mycell = cell_index(g, w.i, w.j, w.k);
           if (COUNT) nS++;
-          if (cell_occupied(g, occ_s, occ_in_lds, mycell)) {
-            mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
-            if (COUNT) nT += mycnt;
-            break;
-          }
+          if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
+        }
+        if (alive) {
+          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+          if (COUNT) nT += mycnt;
         }
       }
     }

@@ -53,7 +53,7 @@ struct rtgpu_ctx {
   BatchHdr *d_hdrs = nullptr;
   float4 *d_nrm = nullptr;
   size_t cap_hdrs = 0;
-  TriRec *d_recs = nullptr;
+  TriRec *d_recs = nullptr, *d_recs_unsorted = nullptr;
   size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
   float lmax = 0.0f;         // longest triangle edge of the uploaded scene
   int64_t known_nrefs = -1;  // reference count of the uploaded scene's grid (it does not depend on the camera)
@@ -264,7 +264,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   resolve_spans(c);
   dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
-  dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs);
+  dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs); dev_free(&c->d_recs_unsorted);
   dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
@@ -434,7 +434,8 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
       for (int k = 0; k < 3; k++) c->known_nv[k] = nv[k];
     }
     if ((size_t)nrefs > c->cap_refs) {
-      if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs)) ||
+      if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_recs_unsorted, (size_t)nrefs)) ||
+          (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs)) ||
           (rc = dev_alloc(c, &c->d_nrm, (size_t)nrefs))) return rc;
       c->cap_refs = nrefs;
     }
@@ -450,7 +451,8 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     hipLaunchKernelGGL(k_batch_counts, dim3((ncells + 255) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_nbatch);
     hipLaunchKernelGGL(k_occupancy, dim3((ncells / 32 + 256) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_occ);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_nbatch, c->d_hdr_start);
-    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs, c->d_refs, c->d_nrm);
+    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs_unsorted, c->d_refs);
+    hipLaunchKernelGGL(k_grid_sort, dim3(ncells), dim3(256), 0, c->stream, g, c->d_recs_unsorted, c->d_recs, c->d_nrm);
     hipLaunchKernelGGL(k_grid_bounds, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, g, c->d_hdrs);
   }
   HIPCHK(c, hipGetLastError());

@@ -63,7 +63,9 @@ def test_no_lights(renderer, tmp_path):
 
 
 @pytest.mark.parametrize("cfg_text", ["voxmode FIXED voxparams 5 4 6\n", "voxmode MODIFIED_DEFAULT voxparams 0.5 2 1.5\n",
-                                      "gamma 1.8 distmod 3.5 voxmode DEFAULT voxparams 1 1 1\n"])
+                                      "gamma 1.8 distmod 3.5 voxmode DEFAULT voxparams 1 1 1\n",
+                                      "voxmode FIXED voxparams 1 1 1\n",      # one cell lists all 1034 triangles: 65 batches, 3 header chunks
+                                      "voxmode FIXED voxparams 64 40 64\n"])  # 163 840 cells: occupancy map too big for LDS, short lists
 def test_voxelisation_modes_and_config_keys(renderer, tmp_path, cfg_text):
     cfg = tmp_path / "r.cfg"
     cfg.write_text(cfg_text)
