@@ -105,7 +105,7 @@ typedef struct rtgpu_counters {
   /* Cell visits of the wavefronts: iterations of the walk kernels' outer loop (only with "count" = 1). */
   int64_t nearest_visits, shadow_visits;
   /* Batches of 16 listed triangles the cell-mode walks looked at, and how many of them were skipped because
-   * no ray of the wavefront could meet the batch's bounding sphere (only with "count" = 1). */
+   * no ray of the wavefront could meet the batch's bounding box (only with "count" = 1). */
   int64_t nearest_batches, nearest_batches_culled, shadow_batches, shadow_batches_culled;
 } rtgpu_counters;
 
@@ -172,6 +172,11 @@ int rtgpu_untile(rtgpu_ctx *ctx, const void *d_gathered, int world, int elem_byt
 int rtgpu_sync(rtgpu_ctx *ctx);
 int rtgpu_counters_get(rtgpu_ctx *ctx, rtgpu_counters *out);
 int rtgpu_timings_get(rtgpu_ctx *ctx, rtgpu_timings *out);
+/* Diagnostic, no counterpart in the reference: shader-clock cycles the wavefronts of the two walk kernels spent
+ * in each of 8 phases (out[0..7] nearest walk, out[8..15] shadow walk: set-up, choice of group and mode, header
+ * staging, batch culling, record staging, triangle tests, stepping, lane/ray modes), summed over all wavefronts
+ * since the last reset.  All zero unless the library was built with -DRT_PHASES (tools/phases.sh). */
+int rtgpu_phase_cycles(rtgpu_ctx *ctx, int64_t out[16], int reset);
 
 /* Single-GPU convenience for a C host: frame_begin must have been called; renders all tiles and
  * returns row-major host arrays (rgb w*h*3, ids w*h, minmax 6).  Any output may be NULL. */

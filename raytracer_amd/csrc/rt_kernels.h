@@ -89,8 +89,8 @@ RT_D Bundle make_bundle(bool in, f3 r, int leader) {
 
 // For the batches of one header chunk and the rays of one bundle: an upper bound of 1 / |cos(ray, normal)|
 // over the batch's triangles, written into the LDS copy of each batch's header.  |cos| >= |axis.n| - rho for
-// the unit normal n.  A triangle the bundle may be coplanar with (bound below 1e-3) makes the batch's value
-// infinite: that batch is not culled in this visit.  One lane per record, 64 records per pass, the normals of
+// the unit normal n.  A triangle the bundle may be coplanar with (bound below 1e-3, or below a quarter of the
+// batch's gb) makes the batch's value infinite: that batch is not culled in this visit.  One lane per record, 64 records per pass, the normals of
 // four passes loaded together (one memory latency); first = index of the chunk's first record, count = its records.
 struct NormalLoads { v4f x[4]; };
 RT_D NormalLoads normal_load4(const float *__restrict__ nrm, uint32_t first, uint32_t count, uint32_t p0, int lane) {
@@ -121,50 +121,98 @@ RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t coun
       }
       c0 = row_minmax16<false>(c0);
       const float cosb = c0 * 0.9999f - bu.rho;
-      const float inv = cosb > 0.001f ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
-      if ((lane & 15) == 15 && p - 15 < count) hs[(p / kBatch) * kHdrFloats + 7] = inv;  // the row's last lane holds its minimum
+      if ((lane & 15) == 15 && p - 15 < count) {  // the row's last lane holds its minimum
+        float *H = hs + (p / kBatch) * kHdrFloats;
+        const float least = __builtin_fmaxf(0.001f, 0.25f * H[11]);  // gb / 4: below it det may change its sign by rounding
+        H[7] = cosb > least ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
 }
 
 // Can the exact test report a hit of the ray (r, m = o x r, odr = o.r, |o| <= onorm) with a triangle of the
-// batch, with a ray parameter in [0, tmax]?  false only if surely not.  H is the batch header in LDS, its
-// inv_cos set by batch_cos for a bundle that contains this ray.
+// batch, with a ray parameter in [0, tmax]?  false only if surely not.  c, radius, h, ga, gb come from the
+// batch header, inv_cos from batch_cos for a bundle that contains this ray.
 //
-// Geometry: a hit point lies on the ray and in a triangle, all triangles lie in the sphere (c, radius), so the
-// ray passes the centre within the radius and the hit's parameter is within the radius of the centre's.
-// Rounding: what the exact test accepts is a point P whose barycentric coordinates are in [0,1] up to
-// eta = E / (2 |det|), with E <= 42 eps L |tv| + 19 eps L^2 the rounding of its numerators (rt_math.h; tv = o - i,
-// L the longest edge) and |det| = |n| |cos| for n = ij x ik and the angle between ray and normal.  P is within
-// 2 eta L of the triangle, and the reported d within (39 eps L^2 |tv| + 36 eps L^3) / |det| of P's parameter:
-//     (81 eps |tv| + 55 eps L) L^2 / (|n| |cos|)  <=  (gb tv + ga) / |cos|,   gb = k1 L / |n|,  ga = 0.4 gb L,  k1 = 144 eps L
-// (batch maxima of ga, gb from k_grid_bounds; tv = |o - c| + radius >= |o - i| for every triangle of the batch).
-// The radius grows by that much.  It comes inflated by 0.1% + 1e-5 |c| from k_grid_bounds and 1e-5 |o| is
-// added here for the rounding of these few operations.  A NaN compares false: not culled.
-RT_D bool sphere_test(f3 c, float radius, bool transparent, float inv_cos, float ga, float gb, float slack, f3 r, f3 m,
-                      float odr, float onorm, float tmax_opaque, bool transparent_counts_anywhere) {
+// Geometry: a hit point lies on the ray's line and in a triangle, and all triangles lie in the box c +- h.  A
+// line meets a box only if no direction r x e_i (e_i the coordinate axes) separates them:
+// |((c - o) x r)_x| <= h_y |r_z| + h_z |r_y| and cyclically; and the parameters of the box's points lie within
+// h.|r| of the centre's parameter tc = (c - o).r.
+// Rounding.  The exact test (intersection.c:58-86) evaluates p = r x ik, det = ij.p, tv = o - i, u det = tv.p,
+// q = tv x ij, v det = r.q, d det = ik.q in binary32 without FMA.  With L the longest edge and eps = 2^-24, a
+// cross product is off by at most 2.83 eps |a||b| and a three-term dot product by 3 eps |a||b| plus what its
+// operands carry, so the numerators of u and v are off by e1 <= 6.83 eps |tv| L, that of d by e3 <= 6.83 eps |tv| L^2
+// and det by e2 <= 5.9 eps L^2.  As long as |det| > e2 (no sign flip), a triangle the test accepts has true
+// barycentric coordinates within eta = (e1 + 1.01 e2) / |det| of [0,1]: the point P where the ray's line meets
+// the plane is within 2 eta L of the triangle, and the reported d within (e3 + (|tv| + 2 L) e2) / |det| of P's
+// parameter.  With |det| = |n| |cos| (n = ij x ik, the angle between ray and normal) both together are at most
+//     (26.4 eps |tv| + 23.7 eps L) L^2 / (|n| |cos|)  <=  (gb tv + ga) / |cos|,   gb = 32 eps L^2 / |n|,  ga = 0.9 gb L
+// (batch maxima of ga, gb from k_grid_bounds; tv = |o - c| + radius >= |o - i| for every triangle of the batch;
+// batch_cos makes 1 / |cos| infinite unless |cos| > gb / 4, which implies |det| > 8 eps L^2 > e2).  On 21 million
+// rays aimed at edges, vertices, slivers and grazing incidence the observed excess stays below 0.14 of this bound.
+// Every half extent grows by that much, W.  The extents come inflated by 0.1% + 1e-5 |c| from k_grid_bounds, and
+// delta = 1e-5 (2 |o| + tv) >= 1e-5 (|o| + |c|), far above the rounding of (c - o) x r and tc, is added to W and to
+// every comparison (the separating direction vanishes for an axis-parallel ray: 0 <= 0 must not be decided by
+// rounding).  A NaN compares false: not culled.
+RT_D bool box_test(f3 c, float radius, f3 h, bool transparent, float inv_cos, float ga, float gb, float slack, f3 r, f3 m,
+                   float odr, float onorm, float tmax_opaque, bool transparent_counts_anywhere) {
   const float ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
   const float ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
   const float ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
   const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
   const float tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
-  const float R0 = __builtin_fmaf(0.00001f, onorm, radius);
-  const float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(tc, tc, d2)), 1.001f, R0);  // |o - c|^2 = d2 + tc^2
-  const float R = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, R0) + slack;
+  const float on5 = 0.00001f * onorm;
+  const float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(tc, tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
+  const float delta = __builtin_fmaf(0.00001f, tv, on5 + on5);
+  const float W = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, delta) + slack;
+  const float hx = h.x + W, hy = h.y + W, hz = h.z + W;
+  const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
+  const float sx = __builtin_fmaf(hy, az, __builtin_fmaf(hz, ay, delta));
+  const float sy = __builtin_fmaf(hx, az, __builtin_fmaf(hz, ax, delta));
+  const float sz = __builtin_fmaf(hx, ay, __builtin_fmaf(hy, ax, delta));
+  const float hr = __builtin_fmaf(hx, ax, __builtin_fmaf(hy, ay, __builtin_fmaf(hz, az, W)));
   // shadow walk: a transparent triangle attenuates wherever it is hit (d >= 0); an opaque one matters only before tmax_opaque
   const float tmax = (transparent_counts_anywhere & transparent) ? INFINITY : tmax_opaque;
-  const bool out = (d2 > R * R * 1.00001f) | (tc + R < 0.0f) | (tc - R > tmax);
+  const bool out = (__builtin_fabsf(ex) > sx) | (__builtin_fabsf(ey) > sy) | (__builtin_fabsf(ez) > sz) | (tc + hr < 0.0f) | (tc - hr > tmax);
   return !out;
 }
-RT_D bool sphere_may_hit(const float *H, float slack, f3 r, f3 m, float odr, float onorm, float tmax_opaque,
-                         bool transparent_counts_anywhere) {
-  const v4f h0 = *reinterpret_cast<const v4f *>(H);       // c, radius
-  const v4f h1 = *reinterpret_cast<const v4f *>(H + 4);   // k1, k2, transparent, inv_cos
-  const v2f h2 = *reinterpret_cast<const v2f *>(H + 8);   // ga, gb
-  return sphere_test(mk3(h0.x, h0.y, h0.z), h0.w, h1.z != 0.0f, h1.w, h2.x, h2.y, slack, r, m, odr, onorm, tmax_opaque,
-                     transparent_counts_anywhere);
-}
+
+// Where a walk kernel's wavefronts spend their time: a diagnostic that exists only in builds with -DRT_PHASES
+// (tools/phases.sh).  end<K>() adds the shader clock since the previous mark to phase K; the sums over all
+// wavefronts land in g_phase (nearest walk 0-7, shadow walk 8-15; rtgpu_phase_cycles reads them).  Phases:
+// 0 ray fetch, set-up and result write, 1 choosing the group and mode of a visit, 2 header staging and
+// batch_cos, 3 batch culling, 4 record staging, 5 triangle tests (3 and 4 are counted in 5 unless RT_PHASES=2),
+// 6 stepping to the next occupied cell, 7 lane and ray mode.
+__device__ unsigned long long g_phase[16];
+#ifdef RT_PHASES
+struct Phases {
+  unsigned long long t0, acc[8];
+  RT_D void begin() {
+    t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0;
+  }
+  template <int K, bool PER_BATCH = false> RT_D void end() {
+    if (PER_BATCH && RT_PHASES < 2) return;  // -DRT_PHASES=2 also separates phases 3, 4, 5 (one mark per batch: heavier)
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[K] += t - t0;
+    t0 = t;
+  }
+  RT_D void flush(int base, int lane) {
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) atomicAdd(&g_phase[base + i], acc[i]);
+    }
+  }
+};
+#else
+struct Phases {
+  RT_D void begin() {}
+  template <int K, bool PER_BATCH = false> RT_D void end() {}
+  RT_D void flush(int, int) {}
+};
+#endif
 
 RT_D void stage_batch(const TriRec *__restrict__ recs, uint32_t c0, int n, float *rs, int lane) {
   const int nvec = n * kRecVecs;
@@ -183,8 +231,8 @@ RT_D void wait_staged() {
 }
 
 // Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
-// batch cull(centre, radius, transparent, inv_cos, ga, gb) decides, for the whole wavefront, whether any of its rays can
-// meet the batch's bounding sphere; only then are the batch's records staged and tested:
+// batch cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides, for the whole wavefront, whether any
+// of its rays can meet the batch's bounding box; only then are the batch's records staged and tested:
 //   batch(k1, k2)      once per surviving batch, with the batch's filter constants
 //   pass1(record)      the side-effect-free first stage of the test (true = this lane cannot reject the
 //                      triangle yet), evaluated for RT_UNROLL records at a time; only if it holds in some
@@ -193,7 +241,8 @@ RT_D void wait_staged() {
 //   more()             (wave-uniform) after each: false = stop.
 template <typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
-                      C &&cull, T &&tally, B &&batch, P &&pass1, F &&f, G &&more) {
+                      Phases &ph, C &&cull, T &&tally, B &&batch, P &&pass1, F &&f, G &&more) {
+  ph.template end<1>();
   float *hs = slice;                             // kHdrChunk headers
   float *rs = slice + kHdrChunk * kHdrFloats;    // kBatch records
   const TriRec *__restrict__ recs = g.cell_tris;
@@ -211,18 +260,21 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
       wait_staged();
       batch_cos(g.cell_nrm, beg + first, count, hs, lane, bundle, f0);
     }
+    ph.template end<2>();
     for (int b = 0; b < nh; ++b) {
       const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, radius
-      const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);   // k1, k2, transparent, inv_cos
-      const v2f h2 = *reinterpret_cast<const v2f *>(hs + b * kHdrFloats + 8);  // ga, gb
-      const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, k.z != 0.0f, k.w, h2.x, h2.y);
+      const v4f hh = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);  // h, inv_cos
+      const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 8);   // k1, -+k2, ga, gb
+      const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w);
       tally(1, keep ? 0 : 1);
+      ph.template end<3, true>();
       if (!keep) continue;
       const uint32_t c0 = beg + (h0 + (uint32_t)b) * kBatch;
       const int n = (int)(beg + cnt - c0 < (uint32_t)kBatch ? beg + cnt - c0 : (uint32_t)kBatch);
       stage_batch(recs, c0, n, rs, lane);
       wait_staged();
-      batch(k.x, k.y);
+      ph.template end<4, true>();
+      batch(k.x, __builtin_fabsf(k.y));
       int j = 0;
       for (; j + RT_UNROLL <= n; j += RT_UNROLL) {
         unsigned long long m[RT_UNROLL], any = 0;
@@ -235,7 +287,7 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
           for (int q = 0; q < RT_UNROLL; q++) {
             if (m[q] != 0) {
               f(rs + (j + q) * kRecFloats, c0 + (uint32_t)(j + q));
-              if (!more()) return;
+              if (!more()) { ph.template end<5>(); return; }
             }
           }
         }
@@ -244,12 +296,14 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
         if (wave_any(pass1(rs + j * kRecFloats))) {
           asm volatile("; some lane passed the first slab");
           f(rs + j * kRecFloats, c0 + (uint32_t)j);
-          if (!more()) return;
+          if (!more()) { ph.template end<5>(); return; }
         }
       }
       __builtin_amdgcn_wave_barrier();
+      ph.template end<5, true>();
     }
     __builtin_amdgcn_wave_barrier();
+    ph.template end<5>();
   }
 }
 constexpr int kSliceFloats = kHdrChunk * kHdrFloats + kBatch * kRecFloats;  // LDS floats per wavefront
@@ -592,7 +646,7 @@ __global__ void __launch_bounds__(256) k_grid_sort(GridP g, const TriRec *__rest
 }
 
 // Grid build, pass 4: the header of every batch of kBatch consecutive records of a cell's list: bounding
-// sphere of the batch's triangles (vertices i, i+ij, i+ik as the exact test sees them), maxima of the
+// box and sphere of the batch's triangles (vertices i, i+ij, i+ik as the exact test sees them), maxima of the
 // records' error constants, transparency flag.  One wavefront per cell, 64 / kBatch batches at a time.
 __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restrict__ hdrs) {
   int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -610,10 +664,10 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restri
     if (valid) {
       const TriRec &R = g.cell_tris[p];
       k1 = R.k1; k2 = R.k2; transparent = R.kt > 0.0f ? 1.0f : 0.0f;
-      // F = k1 (tv + 0.4 L) L / |n| = gb tv + ga  (see sphere_may_hit); L from k1 = 144 eps L
+      // gb = 32 eps L^2 / |n|, ga = 0.9 gb L  (see box_test); L from k1 = 144 eps L
       const float L = R.k1 * (1.0f / (144.0f * 5.9604644775390625e-8f));
-      gb = R.k1 * L / sqrtf(R.n[0] * R.n[0] + R.n[1] * R.n[1] + R.n[2] * R.n[2]) * 1.0001f;
-      ga = 0.4f * gb * L * 1.0001f;
+      gb = (32.0f * 5.9604644775390625e-8f) * L * L / sqrtf(R.n[0] * R.n[0] + R.n[1] * R.n[1] + R.n[2] * R.n[2]) * 1.0001f;
+      ga = 0.9f * gb * L * 1.0001f;
       if (!(gb >= 0.0f) || !(ga >= 0.0f)) bad = 1.0f;  // NaN (degenerate triangle): never cull this batch
       const float *G = g.geom + 9 * (long long)R.id;
 #pragma unroll
@@ -649,8 +703,11 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restri
       h.c[0] = cx; h.c[1] = cy; h.c[2] = cz;
       const float cn = sqrtf(cx * cx + cy * cy + cz * cz);
       h.radius = bad != 0.0f ? INFINITY : (sqrtf(r2) * 1.001f + 0.00001f * cn) * 1.0001f + 1e-30f;
-      h.k1 = k1; h.k2 = k2; h.transparent = transparent; h.inv_cos = INFINITY;
-      h.ga = ga; h.gb = gb; h.pad[0] = h.pad[1] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 3; q++) h.h[q] = bad != 0.0f ? INFINITY : (0.5f * (hi[q] - lo[q]) * 1.001f + 0.00001f * cn) * 1.0001f + 1e-30f;
+      h.inv_cos = INFINITY;
+      h.k1 = k1; h.k2 = transparent != 0.0f ? -k2 : k2;  // k2 > 0 (rt_math.h)
+      h.ga = ga; h.gb = gb;
       hdrs[hbeg + (p - beg) / kBatch] = h;
     }
   }
@@ -740,6 +797,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
   const TriRec *__restrict__ recs = g.cell_tris;
   unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
+  Phases ph;
+  ph.begin();
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&ctl->ticket_nearest[level], 64u);
@@ -778,6 +837,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         if (COUNT) nT += mycnt;
       }
     }
+    ph.end<0>();
     for (;;) {
       const unsigned long long m = __ballot(alive);
       if (m == 0) break;
@@ -819,9 +879,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(proc, r, leader),
-                    [&](f3 c, float radius, bool transparent, float inv_cos, float ga, float gb) {
-                      return wave_any(proc & sphere_test(c, radius, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, best, false));
+        stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(proc, r, leader), ph,
+                    [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
+                      return wave_any(proc & box_test(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, best, false));
                     },
                     [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
                     [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
@@ -870,6 +930,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         }
         if (proc) { best = cb; best_id = cid; best_u = cu; best_v = cv; }
       }
+      ph.end<7>();
       if (proc) {
         if (best_id >= 0) {
           h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v; h.i = w.i; h.j = w.j; h.k = w.k;
@@ -888,10 +949,13 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
           if (COUNT) nT += mycnt;
         }
       }
+      ph.end<6>();
     }
     if (idx < nrays) hits[idx] = h;
     nHits += __popcll(__ballot(h.tri >= 0));
   }
+  ph.end<0>();
+  ph.flush(0, lane);
   if (lane == 0) {
     if (level == 0) {
       atomicAdd(&ctl->stat[kPixels], (unsigned long long)nPixels);
@@ -1085,6 +1149,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
   unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
+  Phases ph;
+  ph.begin();
   for (;;) {
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&ctl->ticket_shadow[level], 64u);
@@ -1141,6 +1207,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
       if (COUNT) nT += mycnt;
     }
+    ph.end<0>();
     for (;;) {
       const unsigned long long m = __ballot(alive);
       if (m == 0) break;
@@ -1184,10 +1251,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(in_group, r, leader),
-                      [&](f3 c, float radius, bool transparent, float inv_cos, float ga, float gb) {
+          stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(in_group, r, leader), ph,
+                      [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
                         return wave_any(in_group & (result >= 0.0f) &
-                                        sphere_test(c, radius, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, dmax, true));
+                                        box_test(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, dmax, true));
                       },
                       [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
                       [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
@@ -1248,6 +1315,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
           if (blocked) { result = -1.0f; alive = false; } else ts = cts;
         }
       }
+      ph.end<7>();
       if (proc && alive) {
         for (;;) {
           dda_step(w);
@@ -1261,9 +1329,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
           if (COUNT) nT += mycnt;
         }
       }
+      ph.end<6>();
     }
     if (have_result) ts_out[(long long)(node_base + nidx) * sp.nslots + slot] = result < 0.0f ? -1.0f : ts;
   }
+  ph.end<0>();
+  ph.flush(8, lane);
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       nS += __shfl_down(nS, off); nT += __shfl_down(nT, off); nQ += __shfl_down(nQ, off); nW += __shfl_down(nW, off);

@@ -38,19 +38,19 @@ static_assert(kBatch == 8 || kBatch == 16 || kBatch == 32 || kBatch == 64, "a wa
 constexpr int kHdrChunk = 32;    // batch headers staged in LDS at a time
 constexpr int kHdrFloats = 12;
 
-// Header of one batch (positions kBatch*b .. kBatch*b + kBatch-1 of a cell's list): a sphere that contains
-// every triangle of the batch (radius already inflated for rounding), the maxima of the records' k1, k2,
-// whether any triangle of the batch is transparent (kt > 0), and the batch's constants ga, gb of the bound
-// of what rounding can add to the sphere (sphere_may_hit in rt_kernels.h).  inv_cos is scratch: the walk
-// kernels keep the visit's bound of 1 / |cos(ray, normal)| for the batch there, in their LDS copy.
+// Header of one batch (positions kBatch*b .. kBatch*b + kBatch-1 of a cell's list): the axis-aligned box
+// (centre c, half extents h) and the sphere (c, radius) that contain every triangle of the batch, both already
+// inflated for rounding; the maxima of the records' k1, k2, with k2 negated if any triangle of the batch is
+// transparent (kt > 0); and the batch's constants ga, gb of the bound of what rounding can add to the box
+// (box_test in rt_kernels.h).  inv_cos is scratch: the walk kernels keep the visit's bound of
+// 1 / |cos(ray, normal)| for the batch there, in their LDS copy.
 struct __attribute__((aligned(16))) BatchHdr {
   float c[3];
   float radius;
-  float k1, k2;
-  float transparent;
+  float h[3];
   float inv_cos;
+  float k1, k2;
   float ga, gb;
-  float pad[2];
 };
 static_assert(sizeof(BatchHdr) == 4 * kHdrFloats, "BatchHdr is 48 bytes");
 

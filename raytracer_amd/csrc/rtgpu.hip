@@ -635,6 +635,20 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   return RTGPU_OK;
 }
 
+int rtgpu_phase_cycles(rtgpu_ctx *c, int64_t out[16], int reset) {
+  if (!c || !out) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[16];
+  HIPCHK(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h));
+  for (int i = 0; i < 16; i++) out[i] = (int64_t)h[i];
+  if (reset) {
+    memset(h, 0, sizeof h);
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof h));
+  }
+  return RTGPU_OK;
+}
+
 int rtgpu_timings_get(rtgpu_ctx *c, rtgpu_timings *out) {
   if (!c || !out) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));

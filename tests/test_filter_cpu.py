@@ -1,13 +1,13 @@
 """The walk kernels' staged triangle filter, restated in numpy and checked against the exact test.
 
 The HIP kernels put a conservative filter (raytracer_amd/csrc/rt_math.h: pl_stage1, pl_stage2,
-pl_surely_inside, pl_sdist; rt_kernels.h: nearest_needs_exact, shadow_verdict, sphere_may_hit) in front
+pl_surely_inside, pl_sdist; rt_kernels.h: nearest_needs_exact, shadow_verdict, box_may_hit) in front
 of the reference's Moeller-Trumbore test (src/intersection.c:58-86).  The filter must never decide
 differently from that test.  Here both are evaluated in float32 on millions of rays, most of them aimed
 at the places where rounding decides (triangle edges and vertices, grazing incidence, slivers, origins
 far from the triangle), and every implication the kernels rely on is asserted:
 
-    exact test accepts              =>  no slab stage rejects, the batch sphere is not culled
+    exact test accepts              =>  no slab stage rejects, the batch's bounding box is not culled
     "surely inside" + sign sure     =>  exact det/u/v tests accept
     distance verdicts               =>  agree with the exact d
 
@@ -115,12 +115,14 @@ def batch_header(T):
     with np.errstate(all="ignore"):
         nn = np.sqrt(N[:, 0] * N[:, 0] + N[:, 1] * N[:, 1] + N[:, 2] * N[:, 2]).astype(F)
         L = T["k1"] * F(1.0 / (144.0 * EPS))
-        gb = (T["k1"] * L / nn * F(1.0001)).astype(F)
-        ga = (F(0.4) * gb * L * F(1.0001)).astype(F)
+        gb = (F(32.0 * EPS) * L * L / nn * F(1.0001)).astype(F)
+        ga = (F(0.9) * gb * L * F(1.0001)).astype(F)
         nrm = (N * (F(1.0) / nn)[:, None]).astype(F)
     bad = ~((gb >= 0) & (ga >= 0))
     radius = np.where(bad, F(np.inf), radius)
-    return dict(c=c, radius=radius, ga=ga, gb=gb, nrm=nrm)
+    h = ((F(0.5) * (hi - lo) * F(1.001) + F(0.00001) * cn[:, None]) * F(1.0001) + F(1e-30)).astype(F)
+    h = np.where(bad[:, None], F(np.inf), h)
+    return dict(c=c, radius=radius, h=h, ga=ga, gb=gb, nrm=nrm)
 
 
 def batch_cos(H, axis, rho):
@@ -130,21 +132,31 @@ def batch_cos(H, axis, rho):
         c0 = np.abs(axis[:, 0] * n[:, 0] + axis[:, 1] * n[:, 1] + axis[:, 2] * n[:, 2])
         c0 = np.where(c0 >= 0, c0, F(0))
         cosb = c0 * F(0.9999) - rho
-        return np.where(cosb > F(0.001), (F(1.0) / cosb).astype(F) * F(1.01), F(np.inf)).astype(F)
+        least = np.maximum(F(0.001), F(0.25) * H["gb"])
+        return np.where(cosb > least, (F(1.0) / cosb).astype(F) * F(1.01), F(np.inf)).astype(F)
 
 
-def sphere_may_hit(H, inv_cos, r, m, odr, onorm, tmax):
-    c = H["c"]
+def box_may_hit(H, inv_cos, r, m, odr, onorm, tmax):
+    """box_test of rt_kernels.h, operation by operation in float32."""
+    c, h = H["c"], H["h"]
+    k = lambda x: np.full_like(onorm, F(x))
     with np.errstate(all="ignore"):
         ex = fma(-c[:, 2], r[:, 1], fma(c[:, 1], r[:, 2], -m[:, 0]))
         ey = fma(-c[:, 0], r[:, 2], fma(c[:, 2], r[:, 0], -m[:, 1]))
         ez = fma(-c[:, 1], r[:, 0], fma(c[:, 0], r[:, 1], -m[:, 2]))
         d2 = fma(ex, ex, fma(ey, ey, ez * ez))
         tc = fma(c[:, 0], r[:, 0], fma(c[:, 1], r[:, 1], fma(c[:, 2], r[:, 2], -odr)))
-        R0 = fma(np.full_like(onorm, F(0.00001)), onorm, H["radius"])
-        tv = fma(np.sqrt(fma(tc, tc, d2)), np.full_like(tc, F(1.001)), R0)
-        R = fma(fma(H["gb"], tv, H["ga"]), inv_cos, R0)
-        out = (d2 > R * R * F(1.00001)) | (tc + R < 0) | (tc - R > tmax)
+        on5 = F(0.00001) * onorm
+        tv = fma(np.sqrt(fma(tc, tc, d2)), k(1.001), on5 + H["radius"])
+        delta = fma(k(0.00001), tv, on5 + on5)
+        W = fma(fma(H["gb"], tv, H["ga"]), inv_cos, delta)
+        hx, hy, hz = h[:, 0] + W, h[:, 1] + W, h[:, 2] + W
+        ax, ay, az = np.abs(r[:, 0]), np.abs(r[:, 1]), np.abs(r[:, 2])
+        sx = fma(hy, az, fma(hz, ay, delta))
+        sy = fma(hx, az, fma(hz, ax, delta))
+        sz = fma(hx, ay, fma(hy, ax, delta))
+        hr = fma(hx, ax, fma(hy, ay, fma(hz, az, W)))
+        out = (np.abs(ex) > sx) | (np.abs(ey) > sy) | (np.abs(ez) > sz) | (tc + hr < 0) | (tc - hr > tmax)
     return ~out
 
 
@@ -232,7 +244,7 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
     assert not (sure_block & ~blocker).any(), "declared a blocker, but the exact test disagrees"
     sure_transparent = inside & (sd - e > 0)
     assert not (sure_transparent & ~acc).any(), "declared an accepted hit, but the exact test rejects (d < 0)"
-    # 5. the bounding sphere of the triangle (as k_grid_bounds builds it), widened by the visit's fuzz, is never
+    # 5. the bounding box of the triangle (as k_grid_bounds builds it), widened by the visit's fuzz, is never
     #    culled for an accepted hit; the bundle is the ray and a second direction up to 2 degrees away
     H = batch_header(T)
     other = (r + (rng.standard_normal((n, 3)) * 10.0 ** rng.uniform(-6, -1.5, (n, 1))).astype(F)).astype(F)
@@ -240,16 +252,49 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
         dlt = r - axis
         rho = (np.sqrt(dot32(dlt, dlt)) * F(1.001) + F(1e-7)).astype(F)
         inv_cos = batch_cos(H, axis, rho)
-        assert sphere_may_hit(H, inv_cos, r, m, odr, onorm, np.full(n, np.inf, F))[acc].all(), "sphere culled an accepted hit"
-        assert sphere_may_hit(H, inv_cos, r, m, odr, onorm, best)[acc & (d < best)].all(), "sphere culled a hit nearer than best"
-        assert sphere_may_hit(H, inv_cos, r, m, odr, onorm, dmax)[blocker].all(), "sphere culled a blocker"
+        assert box_may_hit(H, inv_cos, r, m, odr, onorm, np.full(n, np.inf, F))[acc].all(), "box culled an accepted hit"
+        assert box_may_hit(H, inv_cos, r, m, odr, onorm, best)[acc & (d < best)].all(), "box culled a hit nearer than best"
+        assert box_may_hit(H, inv_cos, r, m, odr, onorm, dmax)[blocker].all(), "box culled a blocker"
     fuzz = batch_cos(H, r, np.full(n, F(1e-7), F))
     # the filter is not vacuous: it rejects most misses and proves most clear hits
     if aim is aim_anywhere:
         assert (~p1 | ~p2)[~acc].mean() > 0.5
-        assert (~sphere_may_hit(H, fuzz, r, m, odr, onorm, np.full(n, np.inf, F)))[~acc].mean() > 0.2
+        assert (~box_may_hit(H, fuzz, r, m, odr, onorm, np.full(n, np.inf, F)))[~acc].mean() > 0.2
     if aim is aim_inside and scale == 1.0 and offset == 0.0:  # (small triangles far from the origin leave little to prove)
         assert inside[acc].mean() > 0.5
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.01, 50.0), (20.0, 300.0), (5.0, -1000.0)])
+def test_box_culling_with_axis_parallel_rays(scale, offset):
+    """Rays along one coordinate axis or inside a coordinate plane: the separating directions r x e_i of the box
+    test vanish there and the comparison must not be decided by rounding."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    a, ab, ac, o, r = make_cases(rng, n, scale, offset, aim_edges)
+    # rebuild the rays: same targets (o + dist r), directions snapped to an axis (two zero components) or a plane (one)
+    dist = np.linalg.norm((a - o).astype(np.float64), axis=1)
+    target = o.astype(np.float64) + r.astype(np.float64) * dist[:, None]
+    keep = rng.integers(0, 3, n)
+    planes = rng.random(n) < 0.5
+    dirn = rng.standard_normal((n, 3))
+    for q in range(3):
+        zero = np.where(planes, keep == q, keep != q)
+        dirn[:, q] = np.where(zero, 0.0, dirn[:, q])
+    dirn /= np.linalg.norm(dirn, axis=1, keepdims=True)
+    o = (target - dirn * dist[:, None]).astype(F)
+    rr = dirn.astype(F)
+    s_ = rr[:, 0] * rr[:, 0] + rr[:, 1] * rr[:, 1] + rr[:, 2] * rr[:, 2]
+    r = rr * (1.0 / np.sqrt(s_.astype(np.float64))).astype(F)[:, None]
+    acc, acc_uv, d, u, v, det = exact_test(a, ab, ac, o, r)
+    assert acc.mean() > 0.1
+    T = preprocess(a, ab, ac)
+    m, onorm, odr = ray_side(o, r)
+    H = batch_header(T)
+    inv_cos = batch_cos(H, r, np.full(n, F(1e-7), F))
+    dmax = (np.abs(d) * rng.uniform(0.5, 1.5, n).astype(F)).astype(F)
+    assert box_may_hit(H, inv_cos, r, m, odr, onorm, np.full(n, np.inf, F))[acc].all()
+    assert box_may_hit(H, inv_cos, r, m, odr, onorm, dmax)[acc & (d < dmax)].all()
+    assert (~box_may_hit(H, inv_cos, r, m, odr, onorm, np.full(n, np.inf, F)))[~acc].mean() > 0.05
 
 
 def test_nan_rays_and_triangles_are_never_rejected():
