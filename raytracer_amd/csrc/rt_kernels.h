@@ -73,17 +73,29 @@ RT_D float wave_max(float x) {
   return lane_bcast(x, 63);
 }
 
-// The directions of the rays a wavefront walks through one cell: the leader's, and rho >= |r - axis| for
-// every ray of the group.
-struct Bundle { f3 axis; float rho; };
-RT_D Bundle make_bundle(bool in, f3 r, int leader) {
+// The rays a wavefront walks through one cell, as a bundle around the leader's ray (direction axis, moment
+// m = o x axis, odr = o.axis): every ray of the group has |r - axis| <= rho, |o - o_leader| <= ro, |o| <= onorm
+// and a parameter range that ends before tmax.
+struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax; };
+RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, float tmax, int leader) {
   Bundle b;
   b.axis = lane_bcast3(r, leader);
-  const f3 dr = sub3(r, b.axis);
+  b.m = lane_bcast3(pm, leader);
+  b.odr = lane_bcast(odr, leader);
+  const f3 dr = sub3(r, b.axis), dorg = sub3(o, lane_bcast3(o, leader));
   // a NaN would be dropped by the max: it becomes +inf (nothing is culled for a group with such a ray)
   float rho = in ? __builtin_amdgcn_sqrtf(dot3(dr, dr)) * 1.001f + 1e-7f : 0.0f;
+  float ro = in ? __builtin_amdgcn_sqrtf(dot3(dorg, dorg)) * 1.001f : 0.0f;
+  float on = in ? onorm : 0.0f;
+  float tm = in ? tmax : -INFINITY;
   if (!(rho >= 0.0f)) rho = INFINITY;
+  if (!(ro >= 0.0f)) ro = INFINITY;
+  if (!(on >= 0.0f)) on = INFINITY;
+  if (tm != tm) tm = INFINITY;
   b.rho = wave_max(rho);
+  b.ro = wave_max(ro);
+  b.onorm = wave_max(on);
+  b.tmax = wave_max(tm);
   return b;
 }
 
@@ -155,17 +167,23 @@ RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t coun
 // delta = 1e-5 (2 |o| + tv) >= 1e-5 (|o| + |c|), far above the rounding of (c - o) x r and tc, is added to W and to
 // every comparison (the separating direction vanishes for an axis-parallel ray: 0 <= 0 must not be decided by
 // rounding).  A NaN compares false: not culled.
+// BUNDLE: the ray is a bundle's leader and the answer is for every ray of the bundle at once (onorm, tmax: the
+// bundle's maxima).  A point of such a ray at parameter t is within ro + |t| rho of the leader's point at t, and
+// |t| <= tv + |h| + 2 W where the ray meets the widened box, so the extents grow by that much more; tv by ro.
+template <bool BUNDLE>
 RT_D bool box_test(f3 c, float radius, f3 h, bool transparent, float inv_cos, float ga, float gb, float slack, f3 r, f3 m,
-                   float odr, float onorm, float tmax_opaque, bool transparent_counts_anywhere) {
+                   float odr, float onorm, float tmax_opaque, bool transparent_counts_anywhere, float ro = 0.0f, float rho = 0.0f) {
   const float ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
   const float ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
   const float ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
   const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
   const float tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
   const float on5 = 0.00001f * onorm;
-  const float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(tc, tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
+  float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(tc, tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
+  if (BUNDLE) tv = __builtin_fmaf(ro, 1.001f, tv);
   const float delta = __builtin_fmaf(0.00001f, tv, on5 + on5);
-  const float W = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, delta) + slack;
+  float W = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, delta) + slack;
+  if (BUNDLE) W += __builtin_fmaf(rho, tv + (h.x + h.y + h.z) + (W + W), ro) * 1.001f;
   const float hx = h.x + W, hy = h.y + W, hz = h.z + W;
   const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
   const float sx = __builtin_fmaf(hy, az, __builtin_fmaf(hz, ay, delta));
@@ -231,8 +249,9 @@ RT_D void wait_staged() {
 }
 
 // Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
-// batch cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides, for the whole wavefront, whether any
-// of its rays can meet the batch's bounding box; only then are the batch's records staged and tested:
+// batch the bundle's leader ray, widened to contain every ray of the bundle, is tested against the batch's box first (one
+// lane per batch); for the batches that remain cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides
+// ray by ray, for the whole wavefront, whether any of its rays can meet the box; only then are the batch's records staged and tested:
 //   batch(k1, k2)      once per surviving batch, with the batch's filter constants
 //   pass1(record)      the side-effect-free first stage of the test (true = this lane cannot reject the
 //                      triangle yet), evaluated for RT_UNROLL records at a time; only if it holds in some
@@ -241,7 +260,7 @@ RT_D void wait_staged() {
 //   more()             (wave-uniform) after each: false = stop.
 template <typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
-                      Phases &ph, C &&cull, T &&tally, B &&batch, P &&pass1, F &&f, G &&more) {
+                      bool transparent_counts_anywhere, Phases &ph, C &&cull, T &&tally, B &&batch, P &&pass1, F &&f, G &&more) {
   ph.template end<1>();
   float *hs = slice;                             // kHdrChunk headers
   float *rs = slice + kHdrChunk * kHdrFloats;    // kBatch records
@@ -261,12 +280,23 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
       batch_cos(g.cell_nrm, beg + first, count, hs, lane, bundle, f0);
     }
     ph.template end<2>();
-    for (int b = 0; b < nh; ++b) {
+    // one lane per batch: can any ray of the bundle meet the batch's box at all?
+    bool maybe = false;
+    if (lane < nh) {
+      const float *H = hs + lane * kHdrFloats;
+      const v4f hc = *reinterpret_cast<const v4f *>(H), hh = *reinterpret_cast<const v4f *>(H + 4), k = *reinterpret_cast<const v4f *>(H + 8);
+      maybe = box_test<true>(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle.axis,
+                             bundle.m, bundle.odr, bundle.onorm, bundle.tmax, transparent_counts_anywhere, bundle.ro, bundle.rho);
+    }
+    const uint32_t candidates = (uint32_t)__ballot(maybe);
+    tally(nh, nh - __popc(candidates));
+    for (uint32_t cm = candidates; cm != 0; cm &= cm - 1) {
+      const int b = __ffs(cm) - 1;
       const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, radius
       const v4f hh = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);  // h, inv_cos
       const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 8);   // k1, -+k2, ga, gb
       const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w);
-      tally(1, keep ? 0 : 1);
+      tally(0, keep ? 0 : 1);
       ph.template end<3, true>();
       if (!keep) continue;
       const uint32_t c0 = beg + (h0 + (uint32_t)b) * kBatch;
@@ -879,9 +909,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(proc, r, leader), ph,
+        stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, ph,
                     [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
-                      return wave_any(proc & box_test(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, best, false));
+                      return wave_any(proc & box_test<false>(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, best, false));
                     },
                     [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
                     [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
@@ -1251,10 +1281,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(in_group, r, leader), ph,
+          stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, ph,
                       [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
                         return wave_any(in_group & (result >= 0.0f) &
-                                        box_test(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, dmax, true));
+                                        box_test<false>(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, dmax, true));
                       },
                       [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
                       [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },

@@ -136,8 +136,8 @@ def batch_cos(H, axis, rho):
         return np.where(cosb > least, (F(1.0) / cosb).astype(F) * F(1.01), F(np.inf)).astype(F)
 
 
-def box_may_hit(H, inv_cos, r, m, odr, onorm, tmax):
-    """box_test of rt_kernels.h, operation by operation in float32."""
+def box_may_hit(H, inv_cos, r, m, odr, onorm, tmax, ro=None, rho=None):
+    """box_test of rt_kernels.h, operation by operation in float32 (ro, rho given: the bundle variant)."""
     c, h = H["c"], H["h"]
     k = lambda x: np.full_like(onorm, F(x))
     with np.errstate(all="ignore"):
@@ -148,8 +148,12 @@ def box_may_hit(H, inv_cos, r, m, odr, onorm, tmax):
         tc = fma(c[:, 0], r[:, 0], fma(c[:, 1], r[:, 1], fma(c[:, 2], r[:, 2], -odr)))
         on5 = F(0.00001) * onorm
         tv = fma(np.sqrt(fma(tc, tc, d2)), k(1.001), on5 + H["radius"])
+        if ro is not None:
+            tv = fma(ro, k(1.001), tv)
         delta = fma(k(0.00001), tv, on5 + on5)
         W = fma(fma(H["gb"], tv, H["ga"]), inv_cos, delta)
+        if ro is not None:
+            W = W + fma(rho, tv + (h[:, 0] + h[:, 1] + h[:, 2]) + (W + W), ro) * F(1.001)
         hx, hy, hz = h[:, 0] + W, h[:, 1] + W, h[:, 2] + W
         ax, ay, az = np.abs(r[:, 0]), np.abs(r[:, 1]), np.abs(r[:, 2])
         sx = fma(hy, az, fma(hz, ay, delta))
@@ -255,6 +259,15 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
         assert box_may_hit(H, inv_cos, r, m, odr, onorm, np.full(n, np.inf, F))[acc].all(), "box culled an accepted hit"
         assert box_may_hit(H, inv_cos, r, m, odr, onorm, best)[acc & (d < best)].all(), "box culled a hit nearer than best"
         assert box_may_hit(H, inv_cos, r, m, odr, onorm, dmax)[blocker].all(), "box culled a blocker"
+        # the bundle variant: the leader's ray (direction axis, origin up to a few triangle sizes away) stands for this ray
+        ol = (o + (rng.standard_normal((n, 3)) * scale * 10.0 ** rng.uniform(-4, 0.5, (n, 1))).astype(F)).astype(F)
+        ml, onl, odl = ray_side(ol, axis)
+        dorg = o - ol
+        ro = (np.sqrt(dot32(dorg, dorg)) * F(1.001)).astype(F)
+        onb = np.maximum(onorm, onl)
+        assert box_may_hit(H, inv_cos, axis, ml, odl, onb, np.full(n, np.inf, F), ro, rho)[acc].all(), "bundle test culled an accepted hit"
+        assert box_may_hit(H, inv_cos, axis, ml, odl, onb, best, ro, rho)[acc & (d < best)].all(), "bundle test culled a nearer hit"
+        assert box_may_hit(H, inv_cos, axis, ml, odl, onb, dmax, ro, rho)[blocker].all(), "bundle test culled a blocker"
     fuzz = batch_cos(H, r, np.full(n, F(1e-7), F))
     # the filter is not vacuous: it rejects most misses and proves most clear hits
     if aim is aim_anywhere:
