@@ -177,6 +177,11 @@ int rtgpu_timings_get(rtgpu_ctx *ctx, rtgpu_timings *out);
  * staging, batch culling, record staging, triangle tests, stepping, lane/ray modes), summed over all wavefronts
  * since the last reset.  All zero unless the library was built with -DRT_PHASES (tools/phases.sh). */
 int rtgpu_phase_cycles(rtgpu_ctx *ctx, int64_t out[16], int reset);
+/* Diagnostic, no counterpart in the reference: per ticket (64 consecutive rays of the level-0 queue) of the nearest
+ * walk (which = 0) or shadow walk (which = 1) of the last chunk: shader clocks, cell visits, batches tested ray by
+ * ray, records tested; 4 uint32 per ticket.  *copied = the number of tickets written, at most max_tickets; 0 unless
+ * the library was built with -DRT_TICKETS (tools/tickets.py). */
+int rtgpu_ticket_log(rtgpu_ctx *ctx, int which, uint32_t *out, int max_tickets, int *copied);
 
 /* Single-GPU convenience for a C host: frame_begin must have been called; renders all tiles and
  * returns row-major host arrays (rgb w*h*3, ids w*h, minmax 6).  Any output may be NULL. */

@@ -58,13 +58,13 @@ RT_D float dpp_minmax(float x) {
   const float y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
   return MAX ? fmaxf(x, y) : fminf(x, y);
 }
-template <bool MAX>
+template <bool MAX, int WIDTH = 16>
 RT_D float row_minmax16(float x) {
   x = dpp_minmax<0x111, 0xf, MAX>(x);  // row_shr:1
   x = dpp_minmax<0x112, 0xf, MAX>(x);  // row_shr:2
   x = dpp_minmax<0x114, 0xf, MAX>(x);  // row_shr:4
-  x = dpp_minmax<0x118, 0xf, MAX>(x);  // row_shr:8
-  return x;
+  if (WIDTH == 16) x = dpp_minmax<0x118, 0xf, MAX>(x);  // row_shr:8
+  return x;  // WIDTH 8: lanes 7 and 15 of a row hold the result of their half
 }
 RT_D float wave_max(float x) {
   x = row_minmax16<true>(x);
@@ -117,7 +117,7 @@ RT_D NormalLoads normal_load4(const float *__restrict__ nrm, uint32_t first, uin
 }
 RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t count, float *hs, int lane, const Bundle &bu,
                     NormalLoads f0) {
-  static_assert(kBatch == 16, "a batch is one DPP row of 16 lanes");
+  static_assert(kBatch == 16 || kBatch == 8, "a batch is a DPP row of 16 lanes or half of one");
   NormalLoads f = f0;
   for (uint32_t p0 = 0; p0 < count; p0 += 256) {
     if (p0 != 0) f = normal_load4(nrm, first, count, p0, lane);
@@ -131,9 +131,9 @@ RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t coun
         c0 = __builtin_fabsf(bu.axis.x * x.x + bu.axis.y * x.y + bu.axis.z * x.z);
         if (!(c0 >= 0.0f)) c0 = 0.0f;  // a NaN must not be dropped by the min below
       }
-      c0 = row_minmax16<false>(c0);
+      c0 = row_minmax16<false, kBatch>(c0);
       const float cosb = c0 * 0.9999f - bu.rho;
-      if ((lane & 15) == 15 && p - 15 < count) {  // the row's last lane holds its minimum
+      if ((lane & (kBatch - 1)) == kBatch - 1 && p - (kBatch - 1) < count) {  // the last lane of a batch holds its minimum
         float *H = hs + (p / kBatch) * kHdrFloats;
         const float least = __builtin_fmaxf(0.001f, 0.25f * H[11]);  // gb / 4: below it det may change its sign by rounding
         H[7] = cosb > least ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
@@ -203,6 +203,30 @@ RT_D bool box_test(f3 c, float radius, f3 h, bool transparent, float inv_cos, fl
 // batch_cos, 3 batch culling, 4 record staging, 5 triangle tests (3 and 4 are counted in 5 unless RT_PHASES=2),
 // 6 stepping to the next occupied cell, 7 lane and ray mode.
 __device__ unsigned long long g_phase[16];
+// Per-ticket log of the walk kernels, only in builds with -DRT_TICKETS (tools/tickets.py): shader clocks from
+// taking the ticket to its last result, cell visits, batches that reached the ray-by-ray test, records tested.
+#ifdef RT_TICKETS
+constexpr int kTicketLog = 1 << 18, kTicketWords = 12;
+__device__ uint32_t g_ticket_log[2][kTicketLog][kTicketWords];
+struct TicketLog {
+  unsigned long long t0; uint32_t visits, batches, tests;
+  RT_D void begin() { t0 = __builtin_amdgcn_s_memtime(); visits = batches = tests = 0; }
+  template <typename PH>
+  RT_D void end(int which, uint32_t base, int lane, PH &ph) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime() - t0;
+    if (lane == 0 && (base >> 6) < (uint32_t)kTicketLog) {
+      uint32_t *e = g_ticket_log[which][base >> 6];
+      e[0] = (uint32_t)t; e[1] = visits; e[2] = batches; e[3] = tests;
+#ifdef RT_PHASES
+      for (int i = 0; i < 8; i++) { e[4 + i] = (uint32_t)ph.acc[i]; ph.acc[i] = 0; }  // with the phase clocks in: per ticket
+#endif
+    }
+  }
+};
+#define RT_TICKET(x) x
+#else
+#define RT_TICKET(x)
+#endif
 #ifdef RT_PHASES
 struct Phases {
   unsigned long long t0, acc[8];
@@ -259,13 +283,13 @@ RT_D void wait_staged() {
 //   f(record, index)   the full test on those records, in list order, checking
 //   more()             (wave-uniform) after each: false = stop.
 template <typename C, typename T, typename B, typename P, typename F, typename G>
-RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
+RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
                       bool transparent_counts_anywhere, Phases &ph, C &&cull, T &&tally, B &&batch, P &&pass1, F &&f, G &&more) {
   ph.template end<1>();
   float *hs = slice;                             // kHdrChunk headers
-  float *rs = slice + kHdrChunk * kHdrFloats;    // kBatch records
+  float *rs = slice + kHdrChunk * kHdrFloats;    // two buffers of kBatch records
   const TriRec *__restrict__ recs = g.cell_tris;
-  const float4 *hsrc = reinterpret_cast<const float4 *>(g.cell_hdrs + g.hdr_start[cell]);
+  const float4 *hsrc = reinterpret_cast<const float4 *>(g.cell_hdrs + hbeg);
   const uint32_t nb = (cnt + kBatch - 1) / kBatch;
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
     const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
@@ -290,6 +314,8 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
     }
     const uint32_t candidates = (uint32_t)__ballot(maybe);
     tally(nh, nh - __popc(candidates));
+    // ray by ray: which of the candidates can any ray of the wavefront meet
+    uint32_t kept = 0;
     for (uint32_t cm = candidates; cm != 0; cm &= cm - 1) {
       const int b = __ffs(cm) - 1;
       const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, radius
@@ -297,36 +323,56 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
       const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 8);   // k1, -+k2, ga, gb
       const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w);
       tally(0, keep ? 0 : 1);
-      ph.template end<3, true>();
-      if (!keep) continue;
-      const uint32_t c0 = beg + (h0 + (uint32_t)b) * kBatch;
-      const int n = (int)(beg + cnt - c0 < (uint32_t)kBatch ? beg + cnt - c0 : (uint32_t)kBatch);
-      stage_batch(recs, c0, n, rs, lane);
+      tally(-1, 0);  // one more batch reached the ray-by-ray test
+      if (keep) kept |= 1u << b;
+    }
+    ph.template end<3>();
+    // the kept batches through two LDS buffers: the next one is on its way while this one is tested
+    auto first_record = [&](int b) { return beg + (h0 + (uint32_t)b) * kBatch; };
+    auto records_of = [&](uint32_t c0) { return (int)(beg + cnt - c0 < (uint32_t)kBatch ? beg + cnt - c0 : (uint32_t)kBatch); };
+    int buf = 0;
+    if (kept != 0) {
+      const uint32_t c0 = first_record(__ffs(kept) - 1);
+      stage_batch(recs, c0, records_of(c0), rs, lane);
+    }
+    while (kept != 0) {
+      const int b = __ffs(kept) - 1;
+      kept &= kept - 1;
+      const uint32_t c0 = first_record(b);
+      const int n = records_of(c0);
+      const float *rb = rs + buf * (kBatch * kRecFloats);
       wait_staged();
+      if (kept != 0) {
+        const uint32_t c1 = first_record(__ffs(kept) - 1);
+        stage_batch(recs, c1, records_of(c1), rs + (buf ^ 1) * (kBatch * kRecFloats), lane);
+      }
+      buf ^= 1;
       ph.template end<4, true>();
+      const v2f k = *reinterpret_cast<const v2f *>(hs + b * kHdrFloats + 8);  // k1, -+k2
       batch(k.x, __builtin_fabsf(k.y));
+      tally(-2, n);  // n records are about to be tested
       int j = 0;
       for (; j + RT_UNROLL <= n; j += RT_UNROLL) {
         unsigned long long m[RT_UNROLL], any = 0;
 #pragma unroll
-        for (int q = 0; q < RT_UNROLL; q++) { m[q] = __ballot(pass1(rs + (j + q) * kRecFloats)); any |= m[q]; }
+        for (int q = 0; q < RT_UNROLL; q++) { m[q] = __ballot(pass1(rb + (j + q) * kRecFloats)); any |= m[q]; }
         asm volatile("" : "+s"(any));
         if (any != 0) {
           asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into per-lane ones
 #pragma unroll
           for (int q = 0; q < RT_UNROLL; q++) {
             if (m[q] != 0) {
-              f(rs + (j + q) * kRecFloats, c0 + (uint32_t)(j + q));
-              if (!more()) { ph.template end<5>(); return; }
+              f(rb + (j + q) * kRecFloats, c0 + (uint32_t)(j + q));
+              if (!more()) { wait_staged(); ph.template end<5>(); return; }
             }
           }
         }
       }
       for (; j < n; ++j) {
-        if (wave_any(pass1(rs + j * kRecFloats))) {
+        if (wave_any(pass1(rb + j * kRecFloats))) {
           asm volatile("; some lane passed the first slab");
-          f(rs + j * kRecFloats, c0 + (uint32_t)j);
-          if (!more()) { ph.template end<5>(); return; }
+          f(rb + j * kRecFloats, c0 + (uint32_t)j);
+          if (!more()) { wait_staged(); ph.template end<5>(); return; }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -336,7 +382,7 @@ RT_D void stream_cell(const GridP &g, int cell, uint32_t beg, uint32_t cnt, floa
     ph.template end<5>();
   }
 }
-constexpr int kSliceFloats = kHdrChunk * kHdrFloats + kBatch * kRecFloats;  // LDS floats per wavefront
+constexpr int kSliceFloats = kHdrChunk * kHdrFloats + 2 * kBatch * kRecFloats;  // LDS floats per wavefront
 
 // Field access of a record in LDS or in memory (float index: n 0-2, k1 3, ik 4-6, q 7-9, id 10, k2 11,
 // ij 12-14, p 15-17, an 18, kt 19).  The first slab needs n, ik, q: two 16-byte reads and one 8-byte read.
@@ -834,6 +880,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     if (lane == 0) base = atomicAdd(&ctl->ticket_nearest[level], 64u);
     base = __builtin_amdgcn_readfirstlane(base);
     if (base >= (uint32_t)nrays) break;
+    RT_TICKET(TicketLog tl; tl.begin();)
     const int idx = base + lane;
     Ray ry;
     ry.i = -2;
@@ -850,7 +897,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     h.d = h.u = h.v = 0.0f; h.i = h.j = h.k = 0; h.pad = 0;
     Dda w;
     int mycell = 0;
-    uint32_t mybeg = 0, mycnt = 0;  // triangle list of mycell
+    uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of mycell and its first batch header
     if (alive) {
       if (COUNT) nQ++;
       dda_init(g, o, r, ry.i, ry.j, ry.k, w);
@@ -863,7 +910,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
       }
       if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
-        mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+        mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
         if (COUNT) nT += mycnt;
       }
     }
@@ -874,10 +921,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       const int leader = __ffsll(m) - 1;
       const int cell = __builtin_amdgcn_readlane(mycell, leader);
       const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
+      const uint32_t hbeg = __builtin_amdgcn_readlane(myhbeg, leader);
       const bool in_group = alive && mycell == cell;
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
+      RT_TICKET(tl.visits++;)
       // exit distance of this voxel: a hit only counts if it lies before it (voxelize.c:569,574)
       float best = min3_ref(w.tx + w.dtx, w.ty + w.dty, w.tz + w.dtz);
       int best_id = -1;
@@ -909,11 +958,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, ph,
+        stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, ph,
                     [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
                       return wave_any(proc & box_test<false>(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, best, false));
                     },
-                    [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
+                    [&](int n, int culled) {
+                      if (n >= 0) { if (COUNT) { nBatch += n; nCull += culled; } }
+                      RT_TICKET(else if (n == -1) tl.batches++; else tl.tests += culled;)
+                    },
                     [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                     [&](const float *R) {
                       if (COUNT) { nWave++; if (proc) nLane++; }
@@ -975,13 +1027,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
           }
         }
         if (alive) {
-          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
           if (COUNT) nT += mycnt;
         }
       }
       ph.end<6>();
     }
     if (idx < nrays) hits[idx] = h;
+    RT_TICKET(ph.end<0>(); if (level == 0) tl.end(0, base, lane, ph);)
     nHits += __popcll(__ballot(h.tri >= 0));
   }
   ph.end<0>();
@@ -1186,6 +1239,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     if (lane == 0) base = atomicAdd(&ctl->ticket_shadow[level], 64u);
     base = __builtin_amdgcn_readfirstlane(base);
     if ((long long)base >= total) break;
+    RT_TICKET(TicketLog tl; tl.begin();)
     const long long item = (long long)base + lane;
     bool alive = false;
     int slot = 0, nidx = 0, current = -1;
@@ -1195,7 +1249,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     Dda w;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int mycell = 0;
-    uint32_t mybeg = 0, mycnt = 0;  // triangle list of mycell
+    uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of mycell and its first batch header
     if (item < total) {
       slot = (int)(item / n);
       nidx = (int)(item - (long long)slot * n);
@@ -1234,7 +1288,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       }
     }
     if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
-      mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+      mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
       if (COUNT) nT += mycnt;
     }
     ph.end<0>();
@@ -1244,10 +1298,12 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       const int leader = __ffsll(m) - 1;
       const int cell = __builtin_amdgcn_readlane(mycell, leader);
       const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
+      const uint32_t hbeg = __builtin_amdgcn_readlane(myhbeg, leader);
       const bool in_group = alive && mycell == cell;
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
+      RT_TICKET(tl.visits++;)
       bool proc;  // this lane's current cell is fully tested (or the ray blocked) after this step
       // One triangle for one shadow ray: 0 = no effect, 2 = accepted hit of a transparent triangle, 3 = opaque
       // blocker inside (1e-5, dmax); the filter decides what it can prove, tri_test the rest (:700-711).
@@ -1281,12 +1337,15 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell(g, cell, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, ph,
+          stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, ph,
                       [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
                         return wave_any(in_group & (result >= 0.0f) &
                                         box_test<false>(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, dmax, true));
                       },
-                      [&](int n, int culled) { if (COUNT) { nBatch += n; nCull += culled; } },
+                      [&](int n, int culled) {
+                        if (n >= 0) { if (COUNT) { nBatch += n; nCull += culled; } }
+                        RT_TICKET(else if (n == -1) tl.batches++; else tl.tests += culled;)
+                      },
                       [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                       [&](const float *R) {
                         if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
@@ -1355,13 +1414,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
           if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
         }
         if (alive) {
-          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg;
+          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
           if (COUNT) nT += mycnt;
         }
       }
       ph.end<6>();
     }
     if (have_result) ts_out[(long long)(node_base + nidx) * sp.nslots + slot] = result < 0.0f ? -1.0f : ts;
+    RT_TICKET(ph.end<0>(); if (level == 0) tl.end(1, base, lane, ph);)
   }
   ph.end<0>();
   ph.flush(8, lane);

@@ -139,12 +139,14 @@ RT_D void dda_init(const GridP &g, f3 o, f3 r, int i, int j, int k, Dda &w) {
 }
 // voxelize.c:594-606 (ties go to the later axis)
 RT_D void dda_step(Dda &w) {
-  float xn = w.tx + w.dtx, yn = w.ty + w.dty, zn = w.tz + w.dtz;
-  if (xn < yn) {
-    if (xn < zn) { w.i += w.di; w.tx = xn; } else { w.k += w.dk; w.tz = zn; }
-  } else {
-    if (yn < zn) { w.j += w.dj; w.ty = yn; } else { w.k += w.dk; w.tz = zn; }
-  }
+  // written with selects: the walk kernels run this in per-lane loops, where branches cost exec-mask bookkeeping
+  const float xn = w.tx + w.dtx, yn = w.ty + w.dty, zn = w.tz + w.dtz;
+  const bool xy = xn < yn;
+  const bool sx = xy & (xn < zn), sy = !xy & (yn < zn);
+  const bool sz = !(sx | sy);
+  w.i += sx ? w.di : 0; w.tx = sx ? xn : w.tx;
+  w.j += sy ? w.dj : 0; w.ty = sy ? yn : w.ty;
+  w.k += sz ? w.dk : 0; w.tz = sz ? zn : w.tz;
 }
 
 // Möller–Trumbore exactly as intersection.c:58-86 evaluates it.

@@ -31,7 +31,7 @@ struct __attribute__((aligned(16))) TriRec {
 static_assert(sizeof(TriRec) == 80, "TriRec is 80 bytes");
 constexpr int kRecFloats = 20;
 #ifndef RT_BATCH
-#define RT_BATCH 16
+#define RT_BATCH 8
 #endif
 constexpr int kBatch = RT_BATCH; // records per batch of a cell's list: the unit of culling and of LDS staging
 static_assert(kBatch == 8 || kBatch == 16 || kBatch == 32 || kBatch == 64, "a wavefront builds the bounds of 64 / kBatch batches at a time");

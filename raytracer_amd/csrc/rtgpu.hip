@@ -649,6 +649,22 @@ int rtgpu_phase_cycles(rtgpu_ctx *c, int64_t out[16], int reset) {
   return RTGPU_OK;
 }
 
+int rtgpu_ticket_log(rtgpu_ctx *c, int which, uint32_t *out, int max_tickets, int *copied) {
+  if (!c || !out || !copied || which < 0 || which > 1) return RTGPU_E_INVALID_PARAM;
+  *copied = 0;
+#ifdef RT_TICKETS
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int n = max_tickets < kTicketLog ? max_tickets : kTicketLog;
+  const size_t entry = sizeof(uint32_t) * kTicketWords;
+  HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ticket_log), entry * (size_t)n, entry * (size_t)kTicketLog * which));
+  *copied = n;
+#else
+  (void)max_tickets;
+#endif
+  return RTGPU_OK;
+}
+
 int rtgpu_timings_get(rtgpu_ctx *c, rtgpu_timings *out) {
   if (!c || !out) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));
