@@ -1,6 +1,6 @@
 // HIP kernels of the trace path (gfx950, wave64).  Included once by rtgpu.hip.
 //
-// Frame set-up          k_preprocess, k_tri_boxes, k_scan_cells, k_grid_fill
+// Frame set-up          k_preprocess, k_tri_boxes, k_grid_offsets, k_grid_fill
 // Pixel loop (a chunk)  k_primary -> [k_nearest -> k_hit] per recursion level -> k_shadow per level
 //                       -> k_accumulate per level, deepest first -> k_minmax_*
 // After the exchange    k_tonemap, k_untile
@@ -550,9 +550,25 @@ __global__ void __launch_bounds__(256) k_tri_boxes(int nt, const float *__restri
       box[6 * t + k] = lo[k];
       box[6 * t + 3 + k] = hi[k];
     }
+  }
+  // a triangle's own lane counts it into a small box of cells; the 64 lanes share the cells of a large one
+  const bool some = valid && hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2];  // (a triangle outside the domain covers no cell)
+  const int ncover = some ? (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) : 0;
+  if (ncover > 0 && ncover <= 32) {
     for (int i = lo[0]; i <= hi[0]; i++)
       for (int j = lo[1]; j <= hi[1]; j++)
         for (int k = lo[2]; k <= hi[2]; k++) atomicAdd(&counts[cell_index(g, i, j, k)], 1u);
+  }
+  for (unsigned long long big = __ballot(ncover > 32); big != 0; big &= big - 1) {
+    const int src = __ffsll(big) - 1;
+    int l[3], ext[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { l[q] = __shfl(lo[q], src); ext[q] = __shfl(hi[q], src) - l[q] + 1; }
+    const int total = ext[0] * ext[1] * ext[2];
+    for (int e = lane_id(); e < total; e += 64) {
+      const int k = e % ext[2], j = (e / ext[2]) % ext[1], i = e / (ext[2] * ext[1]);
+      atomicAdd(&counts[cell_index(g, l[0] + i, l[1] + j, l[2] + k)], 1u);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -566,43 +582,74 @@ __global__ void __launch_bounds__(256) k_tri_boxes(int nt, const float *__restri
   }
 }
 
-// Exclusive scan of the per-cell counts into cell_start[0..ncells] (one 1024-thread block).
-__global__ void __launch_bounds__(1024) k_scan_cells(int n, const uint32_t *__restrict__ counts,
-                                                     uint32_t *__restrict__ start) {
-  __shared__ uint32_t wave_sum[16];
-  __shared__ uint32_t carry_s;
+// Everything that follows from the per-cell counts, in one 1024-thread block: exclusive scans into
+// cell_start[0..ncells] (records) and hdr_start[0..ncells] (batch headers, ceil(count / kBatch) per cell), the list
+// of the non-empty cells (nonempty[0..n), n stored at nonempty[ncells]) and the occupancy bitmap (one bit per cell).
+// Four consecutive cells per thread and step.
+__global__ void __launch_bounds__(1024) k_grid_offsets(int n, const uint32_t *__restrict__ counts, uint32_t *__restrict__ start,
+                                                       uint32_t *__restrict__ hstart, uint32_t *__restrict__ nonempty,
+                                                       uint32_t *__restrict__ occ) {
+  __shared__ uint32_t wave_sum[3][16];
+  __shared__ uint32_t carry_s[3];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) carry_s = 0;
+  if (tid < 3) carry_s[tid] = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    int idx = base + tid;
-    uint32_t v = idx < n ? counts[idx] : 0u, x = v;
+  for (int base = 0; base < n; base += 4096) {
+    const int idx = base + 4 * tid;
+    uint32_t v[4], x[3] = {0, 0, 0};  // records, headers, non-empty cells of this thread's four cells
+    uint32_t bits = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t y = __shfl_up(x, off);
-      if (lane >= off) x += y;
+    for (int q = 0; q < 4; q++) {
+      v[q] = idx + q < n ? counts[idx + q] : 0u;
+      x[0] += v[q]; x[1] += (v[q] + kBatch - 1) / kBatch; x[2] += v[q] > 0u ? 1u : 0u;
+      bits |= (v[q] > 0u ? 1u : 0u) << q;
     }
-    if (lane == 63) wave_sum[wid] = x;
+    // occupancy: 8 threads' four bits make one word (cells idx..idx+3 are bits 4 (tid % 8) .. of word idx / 32)
+    bits <<= 4 * (tid & 7);
+    bits |= __shfl_xor(bits, 1); bits |= __shfl_xor(bits, 2); bits |= __shfl_xor(bits, 4);
+    if ((tid & 7) == 0 && idx < n) occ[idx >> 5] = bits;
+    uint32_t mine[3], incl[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mine[a] = incl[a] = x[a];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(incl[a], off);
+        if (lane >= off) incl[a] += y;
+      }
+      if (lane == 63) wave_sum[a][wid] = incl[a];
+    }
     __syncthreads();
-    uint32_t prefix = carry_s;
-    for (int wv = 0; wv < wid; wv++) prefix += wave_sum[wv];
-    if (idx < n) start[idx] = prefix + x - v;
+    uint32_t pre[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      pre[a] = carry_s[a] + incl[a] - mine[a];
+      for (int wv = 0; wv < wid; wv++) pre[a] += wave_sum[a][wv];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (idx + q < n) {
+        start[idx + q] = pre[0]; hstart[idx + q] = pre[1];
+        if (v[q] > 0u) nonempty[pre[2]] = (uint32_t)(idx + q);
+      }
+      pre[0] += v[q]; pre[1] += (v[q] + kBatch - 1) / kBatch; pre[2] += v[q] > 0u ? 1u : 0u;
+    }
     __syncthreads();
-    if (tid == 1023) carry_s = prefix + x;
+    if (tid == 1023) { carry_s[0] = pre[0]; carry_s[1] = pre[1]; carry_s[2] = pre[2]; }
     __syncthreads();
   }
-  if (tid == 0) start[n] = carry_s;
+  if (tid == 0) { start[n] = carry_s[0]; hstart[n] = carry_s[1]; nonempty[n] = carry_s[2]; }
 }
 
 // Grid build, pass 2: one wavefront per cell walks the triangles in index order, 64 at a time, and
 // appends those whose voxel box contains the cell; ballot + prefix count keeps the list in ascending
 // triangle order, which is the reference's insertion order and therefore its tie-break.
-__global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *__restrict__ box, TriRec *__restrict__ recs,
-                                                   int32_t *__restrict__ refs) {
-  int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (cell >= g.ncells) return;
+__global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const uint32_t *__restrict__ nonempty, const int *__restrict__ box,
+                                                   TriRec *__restrict__ recs, int32_t *__restrict__ refs) {
+  const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= nonempty[g.ncells]) return;
+  const int cell = (int)nonempty[slot];
   uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
-  if (beg == end) return;
   const int lane = lane_id();
   int ck = cell % g.nv[2], cj = (cell / g.nv[2]) % g.nv[1], ci = cell / (g.nv[2] * g.nv[1]);
   uint32_t pos = beg;
@@ -643,7 +690,7 @@ __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const int *_
 // lie close together and their bounding sphere is small; all other lists keep the ascending order.
 // One block per cell; 64-bit keys (class, Morton code, position) sorted with a bitonic network in LDS.
 // Also writes the unit normals of the final order.
-constexpr int kSortMax = 4096;
+constexpr int kSortMax = 4096, kSortThreads = 1024;
 RT_D uint32_t morton10(uint32_t x) {
   x &= 0x3ffu;
   x = (x | (x << 16)) & 0x30000ffu;
@@ -652,20 +699,20 @@ RT_D uint32_t morton10(uint32_t x) {
   x = (x | (x << 2)) & 0x9249249u;
   return x;
 }
-__global__ void __launch_bounds__(256) k_grid_sort(GridP g, const TriRec *__restrict__ src, TriRec *__restrict__ dst,
-                                                   float4 *__restrict__ nrm) {
+__global__ void __launch_bounds__(kSortThreads) k_grid_sort(GridP g, const uint32_t *__restrict__ nonempty, const TriRec *__restrict__ src,
+                                                   TriRec *__restrict__ dst, float4 *__restrict__ nrm) {
   __shared__ unsigned long long keys[kSortMax];
   __shared__ int transparent_s;
-  const int cell = blockIdx.x;
+  if (blockIdx.x >= nonempty[g.ncells]) return;
+  const int cell = (int)nonempty[blockIdx.x];
   const uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
   const int cnt = (int)(end - beg), tid = threadIdx.x;
-  if (cnt == 0) return;
   bool sorted = cnt > 32 && cnt <= kSortMax;
   if (sorted) {
     if (tid == 0) transparent_s = 0;
     __syncthreads();
     int any = 0;
-    for (int j = tid; j < cnt; j += 256) any |= src[beg + j].kt > 0.0f ? 1 : 0;
+    for (int j = tid; j < cnt; j += kSortThreads) any |= src[beg + j].kt > 0.0f ? 1 : 0;
     if (any) atomicOr(&transparent_s, 1);
     __syncthreads();
     sorted = transparent_s == 0;
@@ -676,7 +723,7 @@ __global__ void __launch_bounds__(256) k_grid_sort(GridP g, const TriRec *__rest
     const int ck = cell % g.nv[2], cj = (cell / g.nv[2]) % g.nv[1], ci = cell / (g.nv[2] * g.nv[1]);
     const float lo[3] = {g.dmin[0] + ci * g.cs[0], g.dmin[1] + cj * g.cs[1], g.dmin[2] + ck * g.cs[2]};
     const float big = 0.5f * fmaxf(g.cs[0], fmaxf(g.cs[1], g.cs[2]));
-    for (int j = tid; j < n2; j += 256) {
+    for (int j = tid; j < n2; j += kSortThreads) {
       unsigned long long key = ~0ull;
       if (j < cnt) {
         const float *G = g.geom + 9 * (long long)src[beg + j].id;
@@ -697,7 +744,7 @@ __global__ void __launch_bounds__(256) k_grid_sort(GridP g, const TriRec *__rest
     __syncthreads();
     for (int k = 2; k <= n2; k <<= 1) {
       for (int jj = k >> 1; jj > 0; jj >>= 1) {
-        for (int i = tid; i < n2; i += 256) {
+        for (int i = tid; i < n2; i += kSortThreads) {
           const int l = i ^ jj;
           if (l > i) {
             const unsigned long long x = keys[i], y = keys[l];
@@ -709,7 +756,7 @@ __global__ void __launch_bounds__(256) k_grid_sort(GridP g, const TriRec *__rest
       }
     }
   }
-  for (int j = tid; j < cnt; j += 256) {
+  for (int j = tid; j < cnt; j += kSortThreads) {
     const int from = sorted ? (int)(keys[j] & 0xffffffffull) : j;
     const float4 *S = reinterpret_cast<const float4 *>(src + beg + from);
     float4 *D = reinterpret_cast<float4 *>(dst + beg + j);
@@ -723,15 +770,14 @@ __global__ void __launch_bounds__(256) k_grid_sort(GridP g, const TriRec *__rest
 
 // Grid build, pass 4: the header of every batch of kBatch consecutive records of a cell's list: bounding
 // box and sphere of the batch's triangles (vertices i, i+ij, i+ik as the exact test sees them), maxima of the
-// records' error constants, transparency flag.  One wavefront per cell, 64 / kBatch batches at a time.
-__global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restrict__ hdrs) {
-  int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (cell >= g.ncells) return;
+// records' error constants, transparency flag.  One block per non-empty cell, each wavefront 64 / kBatch batches at a time.
+__global__ void __launch_bounds__(256) k_grid_bounds(GridP g, const uint32_t *__restrict__ nonempty, BatchHdr *__restrict__ hdrs) {
+  if (blockIdx.x >= nonempty[g.ncells]) return;
+  const int cell = (int)nonempty[blockIdx.x];
   const uint32_t beg = g.cell_start[cell], end = g.cell_start[cell + 1];
-  if (beg == end) return;
   const uint32_t hbeg = g.hdr_start[cell];
   const int lane = lane_id();
-  for (uint32_t c0 = beg; c0 < end; c0 += 64) {
+  for (uint32_t c0 = beg + 64u * (threadIdx.x >> 6); c0 < end; c0 += 256) {
     const uint32_t p = c0 + lane;
     const bool valid = p < end;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -788,16 +834,9 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, BatchHdr *__restri
     }
   }
 }
-// One bit per cell: does it list any triangle?  The walk kernels keep this map in LDS (kOccWords words, grids
+// One bit per cell (k_grid_offsets): does it list any triangle?  The walk kernels keep this map in LDS (kOccWords words, grids
 // up to 49 152 cells) so that stepping through empty cells, most of a shadow ray's way to a distant light,
 // costs an LDS read instead of a trip to L2 per step.
-__global__ void k_occupancy(int ncells, const uint32_t *__restrict__ counts, uint32_t *__restrict__ occ) {
-  const int wd = blockIdx.x * blockDim.x + threadIdx.x;
-  if (wd * 32 >= ncells) return;
-  uint32_t bits = 0;
-  for (int b = 0; b < 32 && wd * 32 + b < ncells; b++) bits |= (counts[wd * 32 + b] > 0u ? 1u : 0u) << b;
-  occ[wd] = bits;
-}
 constexpr int kOccWords = 1536;
 // Copies the occupancy map into the block's LDS if it fits; returns whether it did.
 RT_D bool load_occupancy(const GridP &g, uint32_t *occ_s) {
@@ -810,12 +849,6 @@ RT_D bool load_occupancy(const GridP &g, uint32_t *occ_s) {
 RT_D bool cell_occupied(const GridP &g, const uint32_t *occ_s, bool in_lds, int cell) {
   const uint32_t wd = in_lds ? occ_s[cell >> 5] : g.occ[cell >> 5];
   return (wd >> (cell & 31)) & 1u;
-}
-
-// Batches per cell, the input of the scan that gives hdr_start.
-__global__ void k_batch_counts(int ncells, const uint32_t *__restrict__ counts, uint32_t *__restrict__ nb) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < ncells) nb[c] = (counts[c] + kBatch - 1) / kBatch;
 }
 
 // ------------------------------------------------------------------------------------------------

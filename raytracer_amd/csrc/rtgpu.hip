@@ -49,7 +49,7 @@ struct rtgpu_ctx {
   SurfaceD *d_surf = nullptr;
   LightD *d_lights = nullptr;
   PlanarD *d_planar = nullptr;
-  uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr, *d_hdr_start = nullptr, *d_occ = nullptr;
+  uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr /* list of the non-empty cells */, *d_hdr_start = nullptr, *d_occ = nullptr;
   BatchHdr *d_hdrs = nullptr;
   float4 *d_nrm = nullptr;
   size_t cap_hdrs = 0;
@@ -57,6 +57,7 @@ struct rtgpu_ctx {
   size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
   float lmax = 0.0f;         // longest triangle edge of the uploaded scene
   int64_t known_nrefs = -1;  // reference count of the uploaded scene's grid (it does not depend on the camera)
+  int64_t known_nonempty = 0;  // and its number of non-empty cells
   int known_nv[3] = {0, 0, 0};
   // frame
   CameraD cam = {};
@@ -422,15 +423,20 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     Span sp(c, W_GRID);
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), c->stream));
     hipLaunchKernelGGL(k_tri_boxes, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, g, c->d_box, c->d_counts);
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_counts, c->d_cell_start);
-    // The grid depends on the scene and its lights only, so the reference count is read back (a host sync)
-    // for the first frame of a scene and reused afterwards; the lists themselves are rebuilt every frame.
+    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_counts, c->d_cell_start, c->d_hdr_start, c->d_nbatch, c->d_occ);
+    // The grid depends on the scene and its lights only, so the numbers of references and of non-empty cells are
+    // read back (a host sync) for the first frame of a scene and reused afterwards; the lists themselves are
+    // rebuilt every frame.
+    uint32_t nonempty = 0;
     if (c->known_nrefs >= 0 && c->known_nv[0] == nv[0] && c->known_nv[1] == nv[1] && c->known_nv[2] == nv[2]) {
       nrefs = (uint32_t)c->known_nrefs;
+      nonempty = (uint32_t)c->known_nonempty;
     } else {
       HIPCHK(c, hipMemcpyAsync(&nrefs, c->d_cell_start + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(&nonempty, c->d_nbatch + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       c->known_nrefs = nrefs;
+      c->known_nonempty = nonempty;
       for (int k = 0; k < 3; k++) c->known_nv[k] = nv[k];
     }
     if ((size_t)nrefs > c->cap_refs) {
@@ -448,12 +454,11 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     g.cell_tris = c->d_recs;
     g.cell_hdrs = c->d_hdrs;
     g.cell_nrm = reinterpret_cast<const float *>(c->d_nrm);
-    hipLaunchKernelGGL(k_batch_counts, dim3((ncells + 255) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_nbatch);
-    hipLaunchKernelGGL(k_occupancy, dim3((ncells / 32 + 256) / 256), dim3(256), 0, c->stream, ncells, c->d_counts, c->d_occ);
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_nbatch, c->d_hdr_start);
-    hipLaunchKernelGGL(k_grid_fill, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_box, c->d_recs_unsorted, c->d_refs);
-    hipLaunchKernelGGL(k_grid_sort, dim3(ncells), dim3(256), 0, c->stream, g, c->d_recs_unsorted, c->d_recs, c->d_nrm);
-    hipLaunchKernelGGL(k_grid_bounds, dim3((ncells + 3) / 4), dim3(256), 0, c->stream, g, c->d_hdrs);
+    if (nonempty > 0) {  // d_nbatch holds the list of the non-empty cells, its length at [ncells]
+      hipLaunchKernelGGL(k_grid_fill, dim3((nonempty + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_nbatch, c->d_box, c->d_recs_unsorted, c->d_refs);
+      hipLaunchKernelGGL(k_grid_sort, dim3(nonempty), dim3(kSortThreads), 0, c->stream, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs, c->d_nrm);
+      hipLaunchKernelGGL(k_grid_bounds, dim3(nonempty), dim3(256), 0, c->stream, g, c->d_nbatch, c->d_hdrs);
+    }
   }
   HIPCHK(c, hipGetLastError());
   c->grid = g;
