@@ -850,6 +850,21 @@ RT_D bool cell_occupied(const GridP &g, const uint32_t *occ_s, bool in_lds, int 
   const uint32_t wd = in_lds ? occ_s[cell >> 5] : g.occ[cell >> 5];
   return (wd >> (cell & 31)) & 1u;
 }
+// Steps the walk to its next non-empty cell; false = it left its range first.  steps counts the cells entered.
+// Two instances, so that the map is read with an LDS or a global load, not through a generic pointer.
+template <bool IN_LDS, bool COUNT>
+RT_D bool walk_to_occupied(const GridP &g, const uint32_t *occ_s, f3 r, Walk &w, unsigned long long &steps) {
+  for (;;) {
+    if (!walk_step(g, r, w)) return false;
+    if (COUNT) steps++;
+    const uint32_t wd = IN_LDS ? occ_s[w.cell >> 5] : g.occ[w.cell >> 5];
+    if ((wd >> (w.cell & 31)) & 1u) return true;
+  }
+}
+template <bool COUNT>
+RT_D bool walk_to_occupied(const GridP &g, const uint32_t *occ_s, bool in_lds, f3 r, Walk &w, unsigned long long &steps) {
+  return in_lds ? walk_to_occupied<true, COUNT>(g, occ_s, r, w, steps) : walk_to_occupied<false, COUNT>(g, occ_s, r, w, steps);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Primary rays of a chunk of tiles (vectormath.h:108-118, voxelize.c:417-471).  Ray index = local
@@ -928,22 +943,18 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     Hit h;
     h.tri = alive ? -1 : -2;
     h.d = h.u = h.v = 0.0f; h.i = h.j = h.k = 0; h.pad = 0;
-    Dda w;
-    int mycell = 0;
-    uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of mycell and its first batch header
+    Walk w;
+    w.cell = 0;
+    uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
     if (alive) {
       if (COUNT) nQ++;
-      dda_init(g, o, r, ry.i, ry.j, ry.k, w);
+      const int glo[3] = {0, 0, 0}, ghi[3] = {g.nv[0] - 1, g.nv[1] - 1, g.nv[2] - 1};
+      walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, w);
       // stand on the first non-empty cell of the walk (the start voxel counts as visited)
-      for (;;) {
-        mycell = cell_index(g, w.i, w.j, w.k);
-        if (COUNT) nS++;
-        if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
-        dda_step(w);
-        if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
-      }
+      if (COUNT) nS++;
+      if (!cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
       if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
-        mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
+        mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
         if (COUNT) nT += mycnt;
       }
     }
@@ -952,10 +963,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       const unsigned long long m = __ballot(alive);
       if (m == 0) break;
       const int leader = __ffsll(m) - 1;
-      const int cell = __builtin_amdgcn_readlane(mycell, leader);
+      const int cell = __builtin_amdgcn_readlane(w.cell, leader);
       const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
       const uint32_t hbeg = __builtin_amdgcn_readlane(myhbeg, leader);
-      const bool in_group = alive && mycell == cell;
+      const bool in_group = alive && w.cell == cell;
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
@@ -1048,19 +1059,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
       ph.end<7>();
       if (proc) {
         if (best_id >= 0) {
-          h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v; h.i = w.i; h.j = w.j; h.k = w.k;
+          h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v;
+          cell_to_voxel(g, w.cell, h.i, h.j, h.k);
           alive = false;
         } else {
-          for (;;) {
-            dda_step(w);
-            if (w.i < 0 || w.i >= g.nv[0] || w.j < 0 || w.j >= g.nv[1] || w.k < 0 || w.k >= g.nv[2]) { alive = false; break; }
-            mycell = cell_index(g, w.i, w.j, w.k);
-            if (COUNT) nS++;
-            if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
-          }
+          alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
         }
         if (alive) {
-          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
+          mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
           if (COUNT) nT += mycnt;
         }
       }
@@ -1279,10 +1285,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     f3 a = mk3(0, 0, 0), r = mk3(0, 0, 0), pm = mk3(0, 0, 0);  // pm = a x r, onorm >= |a|: the filter's ray side
     float dmax = 0.0f, ts = 1.0f, result = 1.0f, onorm = 0.0f, odr = 0.0f;
     bool have_result = false;
-    Dda w;
-    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    int mycell = 0;
-    uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of mycell and its first batch header
+    Walk w;
+    w.cell = 0;
+    uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
     if (item < total) {
       slot = (int)(item / n);
       nidx = (int)(item - (long long)slot * n);
@@ -1303,25 +1308,20 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
           int ai[3], bi[3];
           // a point outside the grid: the reference reports an error and treats the light as visible (:661-670)
           if (voxel_of(g, a, ai[0], ai[1], ai[2]) && voxel_of(g, b, bi[0], bi[1], bi[2])) {
+            int lo[3], hi[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { lo[c] = ai[c] < bi[c] ? ai[c] : bi[c]; hi[c] = ai[c] < bi[c] ? bi[c] : ai[c]; }
-            dda_init(g, a, r, ai[0], ai[1], ai[2], w);
+            walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, w);
             pl_ray(a, r, pm, onorm, odr);
             alive = true;
-            if (COUNT) nW++;
-            for (;;) {
-              mycell = cell_index(g, w.i, w.j, w.k);
-              if (COUNT) nS++;
-              if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
-              dda_step(w);
-              if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
-            }
+            if (COUNT) { nW++; nS++; }
+            if (!cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
           }
         }
       }
     }
     if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
-      mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
+      mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
       if (COUNT) nT += mycnt;
     }
     ph.end<0>();
@@ -1329,10 +1329,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       const unsigned long long m = __ballot(alive);
       if (m == 0) break;
       const int leader = __ffsll(m) - 1;
-      const int cell = __builtin_amdgcn_readlane(mycell, leader);
+      const int cell = __builtin_amdgcn_readlane(w.cell, leader);
       const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
       const uint32_t hbeg = __builtin_amdgcn_readlane(myhbeg, leader);
-      const bool in_group = alive && mycell == cell;
+      const bool in_group = alive && w.cell == cell;
       const bool is_short = alive && mycnt <= RT_SHORT_LIST;
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
@@ -1439,15 +1439,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       }
       ph.end<7>();
       if (proc && alive) {
-        for (;;) {
-          dda_step(w);
-          if (w.i < lo[0] || w.i > hi[0] || w.j < lo[1] || w.j > hi[1] || w.k < lo[2] || w.k > hi[2]) { alive = false; break; }
-          mycell = cell_index(g, w.i, w.j, w.k);
-          if (COUNT) nS++;
-          if (cell_occupied(g, occ_s, occ_in_lds, mycell)) break;
-        }
+        alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
         if (alive) {
-          mybeg = cstart[mycell]; mycnt = cstart[mycell + 1] - mybeg; myhbeg = g.hdr_start[mycell];
+          mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
           if (COUNT) nT += mycnt;
         }
       }

@@ -149,6 +149,49 @@ RT_D void dda_step(Dda &w) {
   w.k += sz ? w.dk : 0; w.tz = sz ? zn : w.tz;
 }
 
+// The walk kernels' form of the same state: the voxel as its cell index, and per axis the number of steps left
+// before the walk leaves its index range (the grid for a nearest-hit walk, the box spanned by the two end voxels
+// for a shadow walk, voxelize.c:607-611 and :727-735).  An axis only ever moves in the direction of its ray
+// component, so "steps left >= 0" is the reference's two-sided range test.  10 registers instead of 19, which is
+// what keeps the stepping loops free of spills.
+struct Walk {
+  float tx, ty, tz, dtx, dty, dtz;
+  int cell;
+  int nx, ny, nz;
+};
+RT_D void walk_init(const GridP &g, f3 o, f3 r, int i, int j, int k, const int lo[3], const int hi[3], Walk &w) {
+  int di, dj, dk;
+  dda_axis(g.dmin[0], g.cs[0], i, o.x, r.x, w.dtx, w.tx, di);
+  dda_axis(g.dmin[1], g.cs[1], j, o.y, r.y, w.dty, w.ty, dj);
+  dda_axis(g.dmin[2], g.cs[2], k, o.z, r.z, w.dtz, w.tz, dk);
+  w.cell = cell_index(g, i, j, k);
+  w.nx = di > 0 ? hi[0] - i : i - lo[0];
+  w.ny = dj > 0 ? hi[1] - j : j - lo[1];
+  w.nz = dk > 0 ? hi[2] - k : k - lo[2];
+}
+// One step (voxelize.c:594-606, ties go to the later axis); false = the walk has left its range (cell is then invalid).
+RT_D bool walk_step(const GridP &g, f3 r, Walk &w) {
+  const float xn = w.tx + w.dtx, yn = w.ty + w.dty, zn = w.tz + w.dtz;
+  const bool xy = xn < yn;
+  const bool sx = xy & (xn < zn), sy = !xy & (yn < zn);
+  const int stride_x = g.nv[1] * g.nv[2], stride_y = g.nv[2];
+  w.tx = sx ? xn : w.tx;
+  w.ty = sy ? yn : w.ty;
+  w.tz = (sx | sy) ? w.tz : zn;
+  w.nx -= sx ? 1 : 0;
+  w.ny -= sy ? 1 : 0;
+  w.nz -= (sx | sy) ? 0 : 1;
+  const int along = sx ? stride_x : sy ? stride_y : 1;
+  const bool forward = sx ? r.x > 0.0f : sy ? r.y > 0.0f : r.z > 0.0f;  // step = r > 0 ? 1 : -1 (voxelize.c:66-118)
+  w.cell += forward ? along : -along;
+  return (w.nx | w.ny | w.nz) >= 0;
+}
+RT_D void cell_to_voxel(const GridP &g, int cell, int &i, int &j, int &k) {
+  k = cell % g.nv[2];
+  j = (cell / g.nv[2]) % g.nv[1];
+  i = cell / (g.nv[2] * g.nv[1]);
+}
+
 // Möller–Trumbore exactly as intersection.c:58-86 evaluates it.
 RT_D bool tri_test(f3 a, f3 ab, f3 ac, f3 o, f3 r, float &d, float &u, float &v) {
   f3 p = cross3(r, ac);

@@ -15,6 +15,8 @@ def one(scene, w, h, reps):
     from tools.diag import SCENES
     sc = rt.Scene(os.path.join(ROOT, SCENES[scene]), width=w, height=h)
     r = rt.Renderer(0, timing=1)
+    if os.environ.get("RT_WAVES_PER_CU"):  # size of the persistent grids, for libraries built with another RT_WAVES
+        r.set_option("waves_per_cu", int(os.environ["RT_WAVES_PER_CU"]))
     r.upload(sc)
     best = None
     for _ in range(reps):

@@ -53,6 +53,10 @@ def main():
         cyc = log[:, 0]
         print("%s walk %.3f ms: %d tickets, clocks mean %.0f, median %.0f, p99 %.0f, max %d (%.1f x mean); sum/8192 waves = %.0f"
               % (kind, t[kind + "_ms"], len(log), cyc.mean(), np.median(cyc), np.quantile(cyc, 0.99), cyc.max(), cyc.max() / cyc.mean(), cyc.sum() / 8192))
+        if log[:, 4:].sum() > 0:
+            ph = log[:, 4:].sum(0)
+            print("   all tickets, share of the phases (set-up, mode, headers+cos, culling, record staging, tests, stepping, lane/ray mode): "
+                  + " ".join("%.1f%%" % (100.0 * x / ph.sum()) for x in ph))
         for j in np.argsort(-cyc)[:12]:
             where = ""
             if which == 0:
