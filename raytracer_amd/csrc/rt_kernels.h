@@ -477,6 +477,42 @@ RT_D int pick_mode(int group, uint32_t leader_cnt, int short_lanes) {
   return leader_cnt * RT_CELL_COST <= ray_cost ? kCellMode : kRayMode;
 }
 
+// Work distribution of the persistent walk kernels: a ticket is 64 consecutive queue entries, taken from a
+// device-wide counter.  All wavefronts add to the same address, and such atomics are served one after another
+// at the memory side (about 15 ns each, measured: 506 000 tickets took 9 ms whatever the kernels did in between),
+// so a wavefront takes several tickets per atomic when there are many: 1/RT_GRAB_DIV of its fair share, at most
+// RT_GRAB_MAX.  The tickets of one grab lie far apart in the queue (neighbouring tiles cost about the same, and a
+// run of expensive ones in one wavefront would be the last to finish).
+#ifndef RT_GRAB_DIV
+#define RT_GRAB_DIV 4
+#define RT_GRAB_MAX 4
+#endif
+struct Tickets {
+  uint32_t per_grab, stride, slot = 0, taken;  // stride = grabs in all = distance (in tickets) between the tickets of one grab
+  RT_D explicit Tickets(unsigned long long total) {
+    const unsigned long long tickets = (total + 63) / 64, waves = (unsigned long long)gridDim.x * (blockDim.x / 64);
+    const unsigned long long share = tickets / (waves * RT_GRAB_DIV);
+    per_grab = (uint32_t)(share < 1 ? 1 : share > RT_GRAB_MAX ? RT_GRAB_MAX : share);
+    stride = (uint32_t)((tickets + per_grab - 1) / per_grab);
+    taken = per_grab;
+  }
+  // base of the next ticket of this wavefront, false when nothing is left
+  RT_D bool take(uint32_t *counter, unsigned long long total, int lane, uint32_t &base) {
+    for (;;) {
+      if (taken == per_grab) {
+        uint32_t s = 0;
+        if (lane == 0) s = atomicAdd(counter, 1u);
+        slot = __builtin_amdgcn_readfirstlane(s);
+        if (slot >= stride) return false;  // the counter only grows
+        taken = 0;
+      }
+      const unsigned long long b = 64ull * ((unsigned long long)slot + (unsigned long long)taken * stride);
+      taken++;
+      if (b < total) { base = (uint32_t)b; return true; }
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Per-triangle preprocess for one camera (preprocess.c:17-32): ij, ik, unit normal flipped towards
 // the observer, plane offset d.  geom: 9 floats (i, ij, ik); aux: 4 floats (n, d).
@@ -584,15 +620,19 @@ __global__ void __launch_bounds__(256) k_tri_boxes(int nt, const float *__restri
 
 // Everything that follows from the per-cell counts, in one 1024-thread block: exclusive scans into
 // cell_start[0..ncells] (records) and hdr_start[0..ncells] (batch headers, ceil(count / kBatch) per cell), the list
-// of the non-empty cells (nonempty[0..n), n stored at nonempty[ncells]) and the occupancy bitmap (one bit per cell).
+// of the non-empty cells (nonempty[0..n), n stored at nonempty[ncells]), the occupancy bitmap (one bit per cell) and
+// the voxel index box of the non-empty cells.
 // Four consecutive cells per thread and step.
-__global__ void __launch_bounds__(1024) k_grid_offsets(int n, const uint32_t *__restrict__ counts, uint32_t *__restrict__ start,
-                                                       uint32_t *__restrict__ hstart, uint32_t *__restrict__ nonempty,
-                                                       uint32_t *__restrict__ occ) {
+__global__ void __launch_bounds__(1024) k_grid_offsets(int n, int nv1, int nv2, const uint32_t *__restrict__ counts,
+                                                       uint32_t *__restrict__ start, uint32_t *__restrict__ hstart,
+                                                       uint32_t *__restrict__ nonempty, uint32_t *__restrict__ occ,
+                                                       int32_t *__restrict__ occ_box) {
   __shared__ uint32_t wave_sum[3][16];
   __shared__ uint32_t carry_s[3];
+  __shared__ int box_s[6];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid < 3) carry_s[tid] = 0;
+  if (tid < 3) { carry_s[tid] = 0; box_s[tid] = INT_MAX; box_s[3 + tid] = INT_MIN; }
+  int blo[3] = {INT_MAX, INT_MAX, INT_MAX}, bhi[3] = {INT_MIN, INT_MIN, INT_MIN};
   __syncthreads();
   for (int base = 0; base < n; base += 4096) {
     const int idx = base + 4 * tid;
@@ -603,6 +643,11 @@ __global__ void __launch_bounds__(1024) k_grid_offsets(int n, const uint32_t *__
       v[q] = idx + q < n ? counts[idx + q] : 0u;
       x[0] += v[q]; x[1] += (v[q] + kBatch - 1) / kBatch; x[2] += v[q] > 0u ? 1u : 0u;
       bits |= (v[q] > 0u ? 1u : 0u) << q;
+      if (v[q] > 0u) {
+        const int c = idx + q, ijk[3] = {c / (nv2 * nv1), (c / nv2) % nv1, c % nv2};
+#pragma unroll
+        for (int a = 0; a < 3; a++) { blo[a] = min(blo[a], ijk[a]); bhi[a] = max(bhi[a], ijk[a]); }
+      }
     }
     // occupancy: 8 threads' four bits make one word (cells idx..idx+3 are bits 4 (tid % 8) .. of word idx / 32)
     bits <<= 4 * (tid & 7);
@@ -638,6 +683,12 @@ __global__ void __launch_bounds__(1024) k_grid_offsets(int n, const uint32_t *__
     if (tid == 1023) { carry_s[0] = pre[0]; carry_s[1] = pre[1]; carry_s[2] = pre[2]; }
     __syncthreads();
   }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (blo[a] != INT_MAX) { atomicMin(&box_s[a], blo[a]); atomicMax(&box_s[3 + a], bhi[a]); }
+  }
+  __syncthreads();
+  if (tid < 6) occ_box[tid] = box_s[tid];
   if (tid == 0) { start[n] = carry_s[0]; hstart[n] = carry_s[1]; nonempty[n] = carry_s[2]; }
 }
 
@@ -923,11 +974,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
   Phases ph;
   ph.begin();
+  Tickets tickets((unsigned long long)nrays);
   for (;;) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&ctl->ticket_nearest[level], 64u);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base >= (uint32_t)nrays) break;
+    uint32_t base;
+    if (!tickets.take(&ctl->ticket_nearest[level], (unsigned long long)nrays, lane, base)) break;
     RT_TICKET(TicketLog tl; tl.begin();)
     const int idx = base + lane;
     Ray ry;
@@ -949,7 +999,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     if (alive) {
       if (COUNT) nQ++;
       const int glo[3] = {0, 0, 0}, ghi[3] = {g.nv[0] - 1, g.nv[1] - 1, g.nv[2] - 1};
-      walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, w);
+      walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, !COUNT, w);  // (the counting variant reports the reference's step counts)
       // stand on the first non-empty cell of the walk (the start voxel counts as visited)
       if (COUNT) nS++;
       if (!cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
@@ -1273,11 +1323,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
   Phases ph;
   ph.begin();
+  Tickets tickets((unsigned long long)total);
   for (;;) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&ctl->ticket_shadow[level], 64u);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if ((long long)base >= total) break;
+    uint32_t base;
+    if (!tickets.take(&ctl->ticket_shadow[level], (unsigned long long)total, lane, base)) break;
     RT_TICKET(TicketLog tl; tl.begin();)
     const long long item = (long long)base + lane;
     bool alive = false;
@@ -1311,7 +1360,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
             int lo[3], hi[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { lo[c] = ai[c] < bi[c] ? ai[c] : bi[c]; hi[c] = ai[c] < bi[c] ? bi[c] : ai[c]; }
-            walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, w);
+            walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, !COUNT, w);
             pl_ray(a, r, pm, onorm, odr);
             alive = true;
             if (COUNT) { nW++; nS++; }

@@ -61,6 +61,7 @@ struct GridP {
   int32_t ncells;
   const uint32_t *cell_start;  // ncells+1 offsets into cell_tris
   const uint32_t *occ;         // one bit per cell: 1 = its list is not empty
+  const int32_t *occ_box;      // lo[3], hi[3]: voxel index box of the non-empty cells (lo > hi: every cell is empty)
   const TriRec *cell_tris;
   const uint32_t *hdr_start;   // ncells+1 offsets into cell_hdrs (one header per kBatch records of a cell)
   const BatchHdr *cell_hdrs;

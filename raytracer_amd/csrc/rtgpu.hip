@@ -406,12 +406,12 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   if ((size_t)ncells + 1 > c->cap_cells) {
     if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->d_nbatch, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_hdr_start, (size_t)ncells + 1)) ||
-        (rc = dev_alloc(c, &c->d_occ, (size_t)ncells / 32 + 1))) return rc;
+        (rc = dev_alloc(c, &c->d_occ, (size_t)ncells / 32 + 1 + 8))) return rc;  // + the box of the non-empty cells
     c->cap_cells = (size_t)ncells + 1;
   }
   GridP g;
   for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
-  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.occ = c->d_occ; g.cell_hdrs = nullptr; g.cell_nrm = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
+  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.occ = c->d_occ; g.occ_box = reinterpret_cast<const int32_t *>(c->d_occ + ((size_t)ncells / 32 + 1)); g.cell_hdrs = nullptr; g.cell_nrm = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
     Span sp(c, W_PRE);
@@ -423,7 +423,8 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     Span sp(c, W_GRID);
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), c->stream));
     hipLaunchKernelGGL(k_tri_boxes, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, g, c->d_box, c->d_counts);
-    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(1024), 0, c->stream, ncells, c->d_counts, c->d_cell_start, c->d_hdr_start, c->d_nbatch, c->d_occ);
+    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(1024), 0, c->stream, ncells, nv[1], nv[2], c->d_counts, c->d_cell_start, c->d_hdr_start, c->d_nbatch, c->d_occ,
+                       reinterpret_cast<int32_t *>(c->d_occ + ((size_t)ncells / 32 + 1)));
     // The grid depends on the scene and its lights only, so the numbers of references and of non-empty cells are
     // read back (a host sync) for the first frame of a scene and reused afterwards; the lists themselves are
     // rebuilt every frame.
