@@ -32,7 +32,7 @@ struct rtgpu_ctx {
   // options
   bool opt_count = false, opt_timing = false;
   int64_t chunk_bytes = 8ll << 30;
-  int waves_per_cu = 32;
+  int waves_per_cu = 4 * RT_WAVES;  // what the walk kernels are compiled for (their register budget)
   bool filter = true;        // staged triangle filter + batch culling (off: every listed triangle gets the exact test)
   // scene, host side
   bool have_scene = false, have_frame = false;
@@ -288,7 +288,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
-  else if (!strcmp(name, "waves_per_cu")) { if (value < 1 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
+  else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = value == 0 ? 4 * RT_WAVES : (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
   return RTGPU_OK;
 }

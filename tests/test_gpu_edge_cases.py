@@ -118,7 +118,7 @@ def test_frames_are_idempotent_and_independent_of_the_persistent_grid_size(rende
     try:
         c = renderer.render_host()
     finally:
-        renderer.set_option("waves_per_cu", 32)
+        renderer.set_option("waves_per_cu", 0)  # 0 = the default
     for other in (b, c):
         assert np.array_equal(a["ids"], other["ids"])
         assert np.array_equal(a["rgb"].view(np.uint32), other["rgb"].view(np.uint32))
