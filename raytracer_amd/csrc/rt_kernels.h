@@ -482,34 +482,38 @@ RT_D int pick_mode(int group, uint32_t leader_cnt, int short_lanes) {
 // at the memory side (about 15 ns each, measured: 506 000 tickets took 9 ms whatever the kernels did in between),
 // so a wavefront takes several tickets per atomic when there are many: 1/RT_GRAB_DIV of its fair share, at most
 // RT_GRAB_MAX.  The tickets of one grab lie far apart in the queue (neighbouring tiles cost about the same, and a
-// run of expensive ones in one wavefront would be the last to finish).
+// run of expensive ones in one wavefront would be the last to finish).  The last RT_GRAB_TAIL sixteenths of the
+// queue are handed out one ticket at a time, so that the wavefronts finish together whatever a ticket costs.
 #ifndef RT_GRAB_DIV
 #define RT_GRAB_DIV 4
 #define RT_GRAB_MAX 4
 #endif
+#ifndef RT_GRAB_TAIL
+#define RT_GRAB_TAIL 2
+#endif
 struct Tickets {
-  uint32_t per_grab, stride, slot = 0, taken;  // stride = grabs in all = distance (in tickets) between the tickets of one grab
+  uint32_t per_grab, groups, singles, slot = 0, taken;  // slots 0..groups-1: per_grab tickets, `groups` apart; then single tickets
   RT_D explicit Tickets(unsigned long long total) {
     const unsigned long long tickets = (total + 63) / 64, waves = (unsigned long long)gridDim.x * (blockDim.x / 64);
     const unsigned long long share = tickets / (waves * RT_GRAB_DIV);
     per_grab = (uint32_t)(share < 1 ? 1 : share > RT_GRAB_MAX ? RT_GRAB_MAX : share);
-    stride = (uint32_t)((tickets + per_grab - 1) / per_grab);
+    groups = per_grab > 1 ? (uint32_t)(tickets * (16 - RT_GRAB_TAIL) / 16 / per_grab) : 0u;
+    singles = (uint32_t)(tickets - (unsigned long long)groups * per_grab);
     taken = per_grab;
   }
   // base of the next ticket of this wavefront, false when nothing is left
-  RT_D bool take(uint32_t *counter, unsigned long long total, int lane, uint32_t &base) {
-    for (;;) {
-      if (taken == per_grab) {
-        uint32_t s = 0;
-        if (lane == 0) s = atomicAdd(counter, 1u);
-        slot = __builtin_amdgcn_readfirstlane(s);
-        if (slot >= stride) return false;  // the counter only grows
-        taken = 0;
-      }
-      const unsigned long long b = 64ull * ((unsigned long long)slot + (unsigned long long)taken * stride);
-      taken++;
-      if (b < total) { base = (uint32_t)b; return true; }
+  RT_D bool take(uint32_t *counter, int lane, uint32_t &base) {
+    if (taken >= per_grab) {
+      uint32_t s = 0;
+      if (lane == 0) s = atomicAdd(counter, 1u);
+      slot = __builtin_amdgcn_readfirstlane(s);
+      if (slot >= groups + singles) return false;  // the counter only grows
+      taken = slot < groups ? 0u : per_grab - 1u;
     }
+    const uint32_t ticket = slot < groups ? slot + taken * groups : groups * per_grab + (slot - groups);
+    taken++;
+    base = 64u * ticket;
+    return true;
   }
 };
 
@@ -977,7 +981,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
   Tickets tickets((unsigned long long)nrays);
   for (;;) {
     uint32_t base;
-    if (!tickets.take(&ctl->ticket_nearest[level], (unsigned long long)nrays, lane, base)) break;
+    if (!tickets.take(&ctl->ticket_nearest[level], lane, base)) break;
     RT_TICKET(TicketLog tl; tl.begin();)
     const int idx = base + lane;
     Ray ry;
@@ -1326,7 +1330,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   Tickets tickets((unsigned long long)total);
   for (;;) {
     uint32_t base;
-    if (!tickets.take(&ctl->ticket_shadow[level], (unsigned long long)total, lane, base)) break;
+    if (!tickets.take(&ctl->ticket_shadow[level], lane, base)) break;
     RT_TICKET(TicketLog tl; tl.begin();)
     const long long item = (long long)base + lane;
     bool alive = false;
