@@ -1342,8 +1342,15 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     w.cell = 0;
     uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
     if (item < total) {
-      slot = (int)(item / n);
-      nidx = (int)(item - (long long)slot * n);
+      // slot = item / n: one division per wavefront; its 64 items span at most two slots unless the queue is tiny
+      const uint32_t slot0 = base / (uint32_t)n, rest = base - slot0 * (uint32_t)n + (uint32_t)lane;
+      if (n >= 64) {
+        slot = (int)(slot0 + (rest >= (uint32_t)n ? 1u : 0u));
+        nidx = (int)(rest >= (uint32_t)n ? rest - (uint32_t)n : rest);
+      } else {
+        slot = (int)(slot0 + rest / (uint32_t)n);
+        nidx = (int)(rest % (uint32_t)n);
+      }
       const Node nd = nodes[node_base + nidx];
       current = nd.tri;
       if (current >= 0) {
