@@ -4,7 +4,7 @@ The frame is cut into 8x8-pixel tiles dealt round-robin to the ranks (cost per p
 orders of magnitude across an image, so fine interleaving is the load balancer).  Every rank holds the
 whole scene and traces only its tiles; there is exactly one exchange per frame:
 
-  1. all-reduce MIN and MAX of the per-channel colour range (3 floats each): the tone map divides by
+  1. all-reduce of the per-channel colour range (MAX over 6 floats: the negated minima and the maxima): the tone map divides by
      the GLOBAL range (src/raytrace.c:396-399, 433-435 of the reference), so it cannot start earlier;
   2. every rank tone-maps its own tiles to RGBA8;
   3. the RGBA8 tiles (4 B/pixel) are gathered to rank 0, which de-interleaves them into the image.
@@ -33,10 +33,10 @@ def exchange_minmax(minmax, group=None):
     """minmax: tensor [6] = min rgb, max rgb of this rank.  Returns the global range on every rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return minmax
-    lo, hi = minmax[:3].clone(), minmax[3:].clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-    return torch.cat([lo, hi])
+    # one collective: MAX of (-min, max); negation is exact, so this is the MIN of the minima
+    both = torch.cat([-minmax[:3], minmax[3:]])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    return torch.cat([-both[:3], both[3:]])
 
 
 def gather_tiles(local, ntiles, elems_per_pixel=1, dst=0, group=None):
@@ -56,10 +56,15 @@ def gather_tiles(local, ntiles, elems_per_pixel=1, dst=0, group=None):
     if local.numel() < most:
         send = torch.zeros(most, dtype=local.dtype, device=local.device)
         send[:local.numel()] = local
-    parts = [torch.empty(most, dtype=local.dtype, device=local.device) for _ in range(world)] if rank == dst else None
+    parts = whole = None
+    if rank == dst:  # the parts are views of one buffer: nothing to concatenate when every rank owns as many tiles
+        whole = torch.empty(most * world, dtype=local.dtype, device=local.device)
+        parts = list(whole.split(most))
     dist.gather(send, parts, dst=dst, group=group)
     if rank != dst:
         return None
+    if ntiles % world == 0:
+        return whole
     return torch.cat([parts[r][:tile_count(ntiles, r, world) * per_tile] for r in range(world)])
 
 

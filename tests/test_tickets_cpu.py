@@ -1,0 +1,47 @@
+"""The persistent walk kernels' ticket hand-out (struct Tickets in raytracer_amd/csrc/rt_kernels.h), restated:
+whatever the queue length and the number of wavefronts, the slots of the device-wide counter map to every
+ticket exactly once, grouped tickets lie `groups` apart, and the last part of the queue is handed out singly."""
+import numpy as np
+import pytest
+
+GRAB_DIV, GRAB_MAX, GRAB_TAIL = 4, 4, 2  # the defaults of rt_kernels.h
+
+
+def plan(total, waves):
+    tickets = (total + 63) // 64
+    share = tickets // (waves * GRAB_DIV)
+    per_grab = min(max(share, 1), GRAB_MAX)
+    groups = tickets * (16 - GRAB_TAIL) // 16 // per_grab if per_grab > 1 else 0
+    singles = tickets - groups * per_grab
+    return tickets, per_grab, groups, singles
+
+
+def tickets_of_slot(slot, per_grab, groups):
+    if slot < groups:
+        return [slot + k * groups for k in range(per_grab)]
+    return [groups * per_grab + (slot - groups)]
+
+
+@pytest.mark.parametrize("total", [1, 63, 64, 65, 4096, 8294400, 32394792, 1036800 * 6 + 17, 2 ** 31 - 5])
+@pytest.mark.parametrize("waves", [4, 1024, 6144, 8192])
+def test_every_ticket_is_handed_out_exactly_once(total, waves):
+    tickets, per_grab, groups, singles = plan(total, waves)
+    assert 1 <= per_grab <= GRAB_MAX and groups * per_grab + singles == tickets
+    if tickets > 3_000_000:  # the big queues: check the arithmetic, not every ticket
+        slots = np.concatenate([np.arange(0, min(groups, 1000)), np.arange(max(groups - 1000, 0), groups)])
+        t = slots[:, None] + np.arange(per_grab)[None, :] * groups
+        assert t.max() < groups * per_grab and len(np.unique(t)) == t.size
+        assert groups * per_grab + singles - 1 == tickets - 1 and 64 * (tickets - 1) < total <= 64 * tickets
+        return
+    seen = np.zeros(tickets, np.int32)
+    for slot in range(groups + singles):
+        for t in tickets_of_slot(slot, per_grab, groups):
+            seen[t] += 1
+    assert (seen == 1).all()
+    assert 64 * (tickets - 1) < total <= 64 * tickets  # the last ticket is the only partial one
+
+
+def test_small_queues_are_not_grouped_and_large_ones_keep_a_single_ticket_tail():
+    assert plan(16200 * 64, 6144)[1] == 1                      # one rank of eight: two or three tickets per wavefront
+    tickets, per_grab, groups, singles = plan(32394792, 6144)  # temple 4K shadow queue
+    assert per_grab == 4 and singles >= tickets // 8 and groups * 4 >= tickets * 3 // 4
