@@ -9,7 +9,7 @@
 #include "rt_texture.h"
 
 #ifndef RT_UNROLL
-#define RT_UNROLL 2
+#define RT_UNROLL 4
 #endif
 #ifndef RT_WAVES
 #define RT_WAVES 6  // waves per SIMD the two walk kernels are compiled for (80 VGPRs each; with 8 and 64 VGPRs they spill and run 6 % slower)
