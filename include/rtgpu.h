@@ -169,6 +169,14 @@ int rtgpu_tonemap(rtgpu_ctx *ctx, const float *d_rgb, int64_t npixels, const flo
  * rtgpu_tile_count(r)*64 elements of elem_bytes) into a row-major w*h image. */
 int rtgpu_untile(rtgpu_ctx *ctx, const void *d_gathered, int world, int elem_bytes, void *d_image);
 
+/* The pixel rows of rtBitmapSave (src/bitmap.c:453-469) built on the device from a row-major RGBA8 image (the
+ * output of rtgpu_untile): bottom-up, B G R per pixel (bpp 24) or B G R 0 (bpp 32), rows padded to four bytes.
+ * d_rows needs rtgpu_bmp_row_bytes(w, bpp) * h bytes; a host prepends the 54-byte header (rtgpu_bmp_header). */
+int64_t rtgpu_bmp_row_bytes(int32_t width, int32_t bpp);
+int rtgpu_bmp_rows(rtgpu_ctx *ctx, const uint32_t *d_image, int32_t bpp, void *d_rows);
+/* The 54-byte file header rtBitmapSave writes for a width x height image of bpp bits. */
+int rtgpu_bmp_header(int32_t width, int32_t height, int32_t bpp, unsigned char header[54]);
+
 int rtgpu_sync(rtgpu_ctx *ctx);
 int rtgpu_counters_get(rtgpu_ctx *ctx, rtgpu_counters *out);
 int rtgpu_timings_get(rtgpu_ctx *ctx, rtgpu_timings *out);

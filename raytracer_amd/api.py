@@ -121,6 +121,10 @@ def gpu_lib():
         L.rtgpu_render.argtypes = [vp, i32, i32, vp, vp, vp]
         L.rtgpu_tonemap.argtypes = [vp, vp, i64, vp, C.c_float, vp]
         L.rtgpu_untile.argtypes = [vp, vp, i32, i32, vp]
+        L.rtgpu_bmp_row_bytes.argtypes = [i32, i32]
+        L.rtgpu_bmp_row_bytes.restype = C.c_int64
+        L.rtgpu_bmp_rows.argtypes = [vp, vp, i32, vp]
+        L.rtgpu_bmp_header.argtypes = [i32, i32, i32, vp]
         L.rtgpu_sync.argtypes = [vp]
         L.rtgpu_counters_get.argtypes = [vp, C.POINTER(Counters)]
         L.rtgpu_timings_get.argtypes = [vp, C.POINTER(Timings)]
@@ -323,6 +327,22 @@ class Renderer:
 
     def untile(self, gathered, world, elem_bytes, image):
         self._chk(self._L.rtgpu_untile(self._h, _ptr(gathered), world, elem_bytes, _ptr(image)), "rtgpu_untile")
+
+    def bmp_rows(self, image, bpp, rows):
+        """image: device RGBA8 image (row-major), rows: device byte buffer of rtgpu_bmp_row_bytes(w, bpp) * h bytes."""
+        self._chk(self._L.rtgpu_bmp_rows(self._h, _ptr(image), bpp, _ptr(rows)), "rtgpu_bmp_rows")
+
+    def bmp_file(self, image, bpp=24):
+        """The complete BMP file (bytes) of a device RGBA8 image: rows packed on the device, header from the library."""
+        import torch
+        w, h = self.camera.sw, self.camera.sh
+        row = int(self._L.rtgpu_bmp_row_bytes(w, bpp))
+        rows = torch.empty(row * h, dtype=torch.uint8, device=image.device)
+        self.bmp_rows(image, bpp, rows)
+        self.sync()
+        hdr = (C.c_ubyte * 54)()
+        self._chk(self._L.rtgpu_bmp_header(w, h, bpp, hdr), "rtgpu_bmp_header")
+        return bytes(hdr) + rows.cpu().numpy().tobytes()
 
     def sync(self):
         self._chk(self._L.rtgpu_sync(self._h), "rtgpu_sync")

@@ -1690,6 +1690,23 @@ __global__ void __launch_bounds__(256) k_tonemap(const float *__restrict__ rgb, 
   rgba[p] = (ch[0] << 24) | (ch[1] << 16) | (ch[2] << 8);
 }
 
+// BMP pixel rows on the device (bitmap.c:453-469): bottom-up, B G R [0] per pixel, every row padded with zeros to a
+// multiple of four bytes.  One thread per 32-bit word of the output, so the stores coalesce; words = row_bytes / 4.
+__global__ void __launch_bounds__(256) k_bmp_rows(const uint32_t *__restrict__ image, int w, int h, int bytes_pp, int words,
+                                                  uint32_t *__restrict__ rows) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long long)words * h) return;
+  const int y_out = (int)(q / words), wd = (int)(q - (long long)y_out * words);
+  const uint32_t *src = image + (long long)(h - 1 - y_out) * w;
+  uint32_t out = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int byte = 4 * wd + b, x = byte / bytes_pp, ch = byte - x * bytes_pp;
+    if (x < w && ch < 3) out |= ((src[x] >> (8 + 8 * ch)) & 0xffu) << (8 * b);  // pixel = R<<24 | G<<16 | B<<8 (bitmap.h:70)
+  }
+  rows[q] = out;
+}
+
 // Tile-major blocks of all ranks (rank-major, then local tile, then 64 slots) -> row-major image.
 __global__ void __launch_bounds__(256) k_untile(const uint32_t *__restrict__ src, int world, int w, int h, int tiles_x,
                                                 long long ntiles, int words, uint32_t *__restrict__ dst) {

@@ -607,6 +607,35 @@ int rtgpu_untile(rtgpu_ctx *c, const void *d_gathered, int world, int elem_bytes
   return RTGPU_OK;
 }
 
+int64_t rtgpu_bmp_row_bytes(int32_t width, int32_t bpp) {
+  if (width <= 0 || (bpp != 24 && bpp != 32)) return -1;
+  return (int64_t)(4 * ceil(bpp * width / 32.0));  // bitmap.c:457
+}
+
+int rtgpu_bmp_rows(rtgpu_ctx *c, const uint32_t *d_image, int32_t bpp, void *d_rows) {
+  if (!c || !d_image || !d_rows || (bpp != 24 && bpp != 32)) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return RTGPU_E_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int w = c->cam.sw, h = c->cam.sh, words = (int)(rtgpu_bmp_row_bytes(w, bpp) / 4);
+  const long long n = (long long)words * h;
+  hipLaunchKernelGGL(k_bmp_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_image, w, h, bpp / 8, words, (uint32_t *)d_rows);
+  HIPCHK(c, hipGetLastError());
+  return RTGPU_OK;
+}
+
+int rtgpu_bmp_header(int32_t width, int32_t height, int32_t bpp, unsigned char h[54]) {
+  if (!h || width <= 0 || height <= 0 || (bpp != 24 && bpp != 32)) return RTGPU_E_INVALID_PARAM;
+  const uint32_t total = (uint32_t)(54 + rtgpu_bmp_row_bytes(width, bpp) * height);
+  auto wr32 = [](unsigned char *p, uint32_t v) { p[0] = v & 0xff; p[1] = (v >> 8) & 0xff; p[2] = (v >> 16) & 0xff; p[3] = (v >> 24) & 0xff; };
+  memset(h, 0, 54);
+  h[0] = 'B'; h[1] = 'M';
+  wr32(h + 2, total); wr32(h + 10, 54); wr32(h + 14, 40);
+  wr32(h + 18, (uint32_t)width); wr32(h + 22, (uint32_t)height);
+  h[26] = 1; h[28] = (unsigned char)bpp;
+  wr32(h + 34, total - 54);
+  return RTGPU_OK;
+}
+
 int rtgpu_sync(rtgpu_ctx *c) {
   if (!c) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));

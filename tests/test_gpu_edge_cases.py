@@ -184,6 +184,30 @@ def test_ulica_384x216_against_the_reference_frame(renderer):
     assert (d.max(-1) > 0).mean() < 1e-3
 
 
+@pytest.mark.parametrize("w,h,bpp", [(400, 300, 24), (65, 9, 24), (7, 3, 24), (66, 5, 24), (65, 9, 32)])
+def test_bmp_rows_packed_on_the_device_equal_the_host_writer(renderer, tmp_path, w, h, bpp):
+    """rtgpu_bmp_rows + rtgpu_bmp_header against rtBitmapSave (padding of odd widths, bottom-up rows, B G R order);
+    at s3's native size the file also has the reference's digest."""
+    import torch
+    scene = rt.Scene(os.path.join(ROOT, "scenes/s3/s3"), width=w, height=h)
+    renderer.upload(scene)
+    renderer.frame_begin()
+    g = renderer.render_host()
+    rgba = renderer.tonemap_host(g["rgb"], g["minmax"], scene.gamma)
+    data = renderer.bmp_file(torch.from_numpy(rgba.view(np.int32).reshape(-1)).cuda(), bpp)
+    if bpp == 24:
+        out = str(tmp_path / "o.bmp")
+        rt.save_bmp24(rgba, out)
+        assert data == open(out, "rb").read()
+        if (w, h) == (400, 300):
+            assert hashlib.sha256(data).hexdigest() == KNOWN["s3"]["bmp_sha256"]
+    else:
+        row = 4 * w
+        assert len(data) == 54 + row * h and data[28] == 32
+        px = np.frombuffer(data[54:], np.uint8).reshape(h, w, 4)[::-1]
+        assert np.array_equal(px[..., 2], (rgba >> 24) & 0xff) and np.array_equal(px[..., 0], (rgba >> 8) & 0xff) and not px[..., 3].any()
+
+
 def test_command_line_end_to_end(tmp_path):
     """The C host (loaders -> rtVisualizedSceneRaytrace -> ToBitmap -> rtBitmapSave) as a user runs it."""
     k = KNOWN["s3"]
