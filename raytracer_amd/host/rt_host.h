@@ -125,6 +125,8 @@ typedef struct _RT_SceneFlat {
 RT_SceneFlat *rtSceneFlatten(const RT_Scene *scene);
 void rtSceneFlatFree(RT_SceneFlat **flat);
 void rtCameraFlatten(const RT_Camera *cam, rtgpu_camera *out);
+/* The loaders' decimal parser (exact short path, strtof otherwise), exported for the tests. */
+float rtParseFloat(const char *text, int *consumed);
 
 /* preprocess.c: texture switch and texture coordinates (src/preprocess.c:13,41-79).  The geometric
  * part of the reference's preprocess (normals, edges) is computed on the GPU per frame and copied

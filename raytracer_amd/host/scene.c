@@ -53,6 +53,68 @@ static void shrink_vertex(RT_Scene *s, float *p, const float *centroid) {
   grow(s, p);
 }
 
+/* sscanf("%f %f %f") and sscanf("%d %d %d") without the format interpreter (the geometry file is 1.7 MB of such
+ * lines).  A decimal with at most 7 significant digits and at most 10 decimals, which is every number of the
+ * bundled scenes, is converted on the exact path: its digits as an integer below 2^24 and the power of ten are
+ * both exact binary32 values, so one correctly rounded division gives the correctly rounded result, the same
+ * value strtof returns.  Anything else (more digits, exponents, inf, nan, hex) goes to strtof itself.  A field
+ * that does not parse stops the line and leaves the remaining outputs as they were, as sscanf does. */
+static float parse_float(const char *p, char **end) {
+  static const float pow10[11] = {1.0f, 10.0f, 100.0f, 1000.0f, 10000.0f, 100000.0f, 1000000.0f, 10000000.0f,
+                                  100000000.0f, 1000000000.0f, 10000000000.0f};
+  const char *q = p;
+  unsigned m = 0;
+  int digits = 0, sig = 0, decimals = 0, neg = 0;
+  while (*q == ' ' || (*q >= '\t' && *q <= '\r')) q++;
+  if (*q == '-') { neg = 1; q++; } else if (*q == '+') q++;
+  for (; *q >= '0' && *q <= '9'; q++, digits++) { if (m || *q != '0') sig++; m = m * 10u + (unsigned)(*q - '0'); if (sig > 7) goto slow; }
+  if (*q == '.') {
+    for (q++; *q >= '0' && *q <= '9'; q++, digits++, decimals++) { if (m || *q != '0') sig++; m = m * 10u + (unsigned)(*q - '0'); if (sig > 7) goto slow; }
+  }
+  if (digits == 0 || decimals > 10 || *q == 'e' || *q == 'E' || *q == 'x' || *q == 'X' || *q == 'p' || *q == 'P') goto slow;
+  *end = (char *)q;
+  {
+    const float x = (float)m / pow10[decimals];
+    return neg ? -x : x;
+  }
+slow:
+  return strtof(p, end);
+}
+/* For the tests: parse_float and how many characters it consumed. */
+float rtParseFloat(const char *text, int *consumed) {
+  char *end;
+  float x = parse_float(text, &end);
+  if (consumed) *consumed = (int)(end - text);
+  return x;
+}
+static void scan_floats(const char *p, float *out, int n) {
+  int k;
+  for (k = 0; k < n; k++) {
+    char *end;
+    float x = parse_float(p, &end);
+    if (end == p) return;
+    out[k] = x; p = end;
+  }
+}
+static void scan_ints(const char *p, int *out, int n) {
+  int k;
+  for (k = 0; k < n; k++) {
+    const char *q = p;
+    long x = 0;
+    int neg = 0, digits = 0;
+    while (*q == ' ' || (*q >= '\t' && *q <= '\r')) q++;
+    if (*q == '-') { neg = 1; q++; } else if (*q == '+') q++;
+    for (; *q >= '0' && *q <= '9' && digits < 9; q++, digits++) x = x * 10 + (*q - '0');
+    if (digits == 0 || (*q >= '0' && *q <= '9')) {  /* nothing, or too long for the short path */
+      char *end;
+      x = strtol(p, &end, 10);
+      if (end == p) return;
+      q = end; neg = 0;
+    }
+    out[k] = (int)(neg ? -x : x); p = q;
+  }
+}
+
 RT_Scene *rtSceneLoad(const char *filename) {
   enum { WANT_NV, VERTS, WANT_NT, TRIS, SIDS, DONE } state = WANT_NV;
   FILE *f = fopen(filename, "r");
@@ -73,7 +135,7 @@ RT_Scene *rtSceneLoad(const char *filename) {
         at = 0; state = left > 0 ? VERTS : WANT_NT;
         break;
       case VERTS:
-        sscanf(line, "%f %f %f", &v[at][0], &v[at][1], &v[at][2]);
+        scan_floats(line, v[at], 3);
         grow(s, v[at]);
         at++;
         if (--left == 0) state = WANT_NT;
@@ -86,10 +148,11 @@ RT_Scene *rtSceneLoad(const char *filename) {
         at = 0; state = left > 0 ? TRIS : SIDS;
         break;
       case TRIS: {
-        int a = 0, b = 0, c = 0;
+        int abc[3] = {0, 0, 0}, a, b, c;
         float cen[3];
         RT_Triangle *t = &s->t[at];
-        sscanf(line, "%d %d %d", &a, &b, &c);
+        scan_ints(line, abc, 3);
+        a = abc[0]; b = abc[1]; c = abc[2];
         memcpy(t->i, v[a], 12); memcpy(t->j, v[b], 12); memcpy(t->k, v[c], 12);
         t->ti[0] = 0.0f; t->ti[1] = 0.0f; t->tj[0] = 1.0f; t->tj[1] = 0.0f; t->tk[0] = 0.0f; t->tk[1] = 1.0f;
         for (k = 0; k < 3; k++) cen[k] = (t->i[k] + t->j[k] + t->k[k]) / 3.0f;
@@ -104,7 +167,7 @@ RT_Scene *rtSceneLoad(const char *filename) {
         char *tok;
         for (tok = strtok(line, " \t\n\r"); tok; tok = strtok(NULL, " \t\n\r")) {
           int sid = 0;
-          sscanf(tok, "%d", &sid);
+          scan_ints(tok, &sid, 1);
           if (at < s->nt) { s->t[at].sid = sid; s->t[at].s = NULL; }
           at++;
         }

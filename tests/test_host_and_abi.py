@@ -93,3 +93,40 @@ def test_cli_binary_prints_help():
     import subprocess
     out = subprocess.run([os.path.join(ROOT, "raytracer_amd", "raytrace")], capture_output=True, text=True)
     assert out.returncode == 0 and "usage:" in out.stdout
+
+
+def test_loader_float_parser_equals_strtof():
+    """The geometry loader converts short decimals itself (one exact division) and must return what sscanf("%f")
+    = strtof returns, bit for bit, and stop at the same character, on every input."""
+    import ctypes as C
+    import random
+    H = rt.host_lib()
+    H.rtParseFloat.restype = C.c_float
+    H.rtParseFloat.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    libc = C.CDLL("libc.so.6")
+    libc.strtof.restype = C.c_float
+    libc.strtof.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+
+    def both(text):
+        b = text.encode()
+        n = C.c_int(0)
+        x = H.rtParseFloat(b, C.byref(n))
+        buf = C.create_string_buffer(b)
+        end = C.c_char_p()
+        y = libc.strtof(buf, C.byref(end))
+        used = C.cast(end, C.c_void_p).value - C.addressof(buf)
+        return np.float32(x).view(np.uint32), n.value, np.float32(y).view(np.uint32), used
+
+    edge = ["", "abc", " 12.5 7", "1e5", "1E-3", "0x10", "nan", "inf", "-inf", "-0.0000", ".5", "5.", "-.25x", "+3.1400",
+            "1234567.8", "0.00000012345678", "00012.3400", "9999999", "16777217", "0.12345678901", "1.00000000000", "--1",
+            "\t\n 23.6853 0.0000", "4294967296.5", "0.0000001", "1234567", "123.4567e", "7.5p3"]
+    rng = random.Random(7)
+    for _ in range(300000):
+        m = rng.randrange(0, 20000000)
+        d = rng.randrange(0, 12)
+        digits = str(m)
+        text = ("0." + digits.rjust(d, "0")) if d >= len(digits) else digits[:len(digits) - d] + ("." + digits[len(digits) - d:] if d else "")
+        edge.append(("-" if rng.random() < 0.5 else "") + text)
+    for text in edge:
+        a, na, b, nb = both(text)
+        assert (a, na) == (b, nb), text
