@@ -159,6 +159,20 @@ int64_t rtgpu_tile_count(const rtgpu_ctx *ctx, int rank, int world);
  * Asynchronous on the context's stream; rtgpu_sync waits. */
 int rtgpu_render(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax);
 
+/* rtgpu_render in two halves, for planar lights on several GPUs.  The reference draws rand() per shaded hit in
+ * pixel order (src/raytrace.c:241-262, each pixel's ray tree in post-order), so a rank has to know how many shaded
+ * hits the pixels before its own have, on whichever rank they are:
+ *   rtgpu_render_trace   primary rays, nearest-hit walks and hit kernels of this rank's tiles (one chunk);
+ *   rtgpu_hit_counts     d_counts[rtgpu_tile_count(rank, world) * 64]: shaded hits per pixel of this rank, tile-major;
+ *   (the host gathers every rank's counts: d_all_counts[world][per_rank], per_rank >= the largest share, and
+ *    their sum total_hits)
+ *   rtgpu_render_shade   rand() order, shadow walks, colours, colour range: the outputs of rtgpu_render.
+ * Without planar lights, or with world = 1, d_all_counts may be NULL and the pair equals rtgpu_render. */
+int rtgpu_render_trace(rtgpu_ctx *ctx, int rank, int world);
+int rtgpu_hit_counts(rtgpu_ctx *ctx, int32_t *d_counts);
+int rtgpu_render_shade(rtgpu_ctx *ctx, const int32_t *d_all_counts, int64_t per_rank, int64_t total_hits, float *d_rgb,
+                       int32_t *d_ids, float *d_minmax);
+
 /* rtVisualizedSceneToBitmap's per-pixel map (src/raytrace.c:433-466) on n pixels in any order:
  * rgba = R<<24 | G<<16 | B<<8 (src/bitmap.h:70) of trunc(pow((c-min)*delta, gamma)*255).
  * d_minmax holds the GLOBAL min/max (after the exchange between ranks). */

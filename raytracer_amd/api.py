@@ -119,6 +119,9 @@ def gpu_lib():
         L.rtgpu_tile_count.restype = i64
         L.rtgpu_tile_count.argtypes = [vp, i32, i32]
         L.rtgpu_render.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.rtgpu_render_trace.argtypes = [vp, i32, i32]
+        L.rtgpu_hit_counts.argtypes = [vp, vp]
+        L.rtgpu_render_shade.argtypes = [vp, vp, i64, i64, vp, vp, vp]
         L.rtgpu_tonemap.argtypes = [vp, vp, i64, vp, C.c_float, vp]
         L.rtgpu_untile.argtypes = [vp, vp, i32, i32, vp]
         L.rtgpu_bmp_row_bytes.argtypes = [i32, i32]
@@ -320,6 +323,17 @@ class Renderer:
     def render(self, rgb, ids, minmax, rank=0, world=1):
         """rgb/ids/minmax: device buffers (torch CUDA tensors or raw pointers), tile-major."""
         self._chk(self._L.rtgpu_render(self._h, rank, world, _ptr(rgb), _ptr(ids), _ptr(minmax)), "rtgpu_render")
+
+    def render_trace(self, rank=0, world=1):
+        """First half of render(): everything up to the hits (see rtgpu_render_trace)."""
+        self._chk(self._L.rtgpu_render_trace(self._h, rank, world), "rtgpu_render_trace")
+
+    def hit_counts(self, counts):
+        self._chk(self._L.rtgpu_hit_counts(self._h, _ptr(counts)), "rtgpu_hit_counts")
+
+    def render_shade(self, rgb, ids, minmax, all_counts=None, per_rank=0, total_hits=-1):
+        self._chk(self._L.rtgpu_render_shade(self._h, _ptr(all_counts) if all_counts is not None else None, per_rank, total_hits,
+                                             _ptr(rgb), _ptr(ids), _ptr(minmax)), "rtgpu_render_shade")
 
     def tonemap(self, rgb, npixels, minmax, gamma, rgba):
         self._chk(self._L.rtgpu_tonemap(self._h, _ptr(rgb), int(npixels), _ptr(minmax), C.c_float(gamma), _ptr(rgba)),

@@ -1239,8 +1239,11 @@ __global__ void __launch_bounds__(256) k_subtree_hits(const Node *__restrict__ n
   if (v.refr >= 0) s += size[v.refr];
   size[node_base + idx] = s;
 }
-__global__ void __launch_bounds__(1024) k_tree_starts(int w, int h, int tiles_x, const int32_t *__restrict__ size,
-                                                      int32_t *__restrict__ rank) {
+// Pixel-order scan of the level-0 subtree sizes of the whole image.  sizes: per rank `per_rank` entries, tile-major in
+// the rank's own tile numbering (tile t of the image is tile t / world of rank t % world); the ranks of this rank's own
+// pixels go to `rank` (its level-0 nodes).  world = 1: sizes is the rank's own array.
+__global__ void __launch_bounds__(1024) k_tree_starts(int w, int h, int tiles_x, const int32_t *__restrict__ sizes,
+                                                      long long per_rank, int world, int me, int32_t *__restrict__ rank) {
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1250,11 +1253,13 @@ __global__ void __launch_bounds__(1024) k_tree_starts(int w, int h, int tiles_x,
   for (int base = 0; base < n; base += 1024) {
     int p = base + tid;
     uint32_t v = 0;
-    int node = 0;
+    int node = 0, owner = 0;
     if (p < n) {
       int x = p % w, y = p / w;
-      node = ((y >> 3) * tiles_x + (x >> 3)) * kTilePixels + (y & 7) * kTile + (x & 7);
-      v = (uint32_t)size[node];
+      const int tile = (y >> 3) * tiles_x + (x >> 3);
+      owner = tile % world;
+      node = (tile / world) * kTilePixels + (y & 7) * kTile + (x & 7);
+      v = (uint32_t)sizes[owner * per_rank + node];
     }
     uint32_t x = v;
 #pragma unroll
@@ -1266,7 +1271,7 @@ __global__ void __launch_bounds__(1024) k_tree_starts(int w, int h, int tiles_x,
     __syncthreads();
     uint32_t prefix = carry_s;
     for (int wv = 0; wv < wid; wv++) prefix += wave_sum[wv];
-    if (p < n) rank[node] = (int32_t)(prefix + x - v);
+    if (p < n && owner == me) rank[node] = (int32_t)(prefix + x - v);
     __syncthreads();
     if (tid == 1023) carry_s = prefix + x;
     __syncthreads();

@@ -58,6 +58,9 @@ struct rtgpu_ctx {
   float lmax = 0.0f;         // longest triangle edge of the uploaded scene
   int64_t known_nrefs = -1;  // reference count of the uploaded scene's grid (it does not depend on the camera)
   int64_t known_nonempty = 0;  // and its number of non-empty cells
+  // a frame rendered in two halves (rtgpu_render_trace ... rtgpu_render_shade): tiles of the share, -1 = none pending
+  int64_t split_tiles = -1;
+  int split_rank = 0, split_world = 1;
   int known_nv[3] = {0, 0, 0};
   // frame
   CameraD cam = {};
@@ -491,98 +494,188 @@ int64_t rtgpu_tile_count(const rtgpu_ctx *c, int rank, int world) {
   return tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
 }
 
-int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax) {
-  if (!c || !d_rgb || !d_ids || !d_minmax || world <= 0 || rank < 0 || rank >= world) return RTGPU_E_INVALID_PARAM;
-  if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
-  if (c->npl > 0 && world != 1)
-    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights need the whole image on one GPU (rand() replay order)");
-  HIPCHK(c, hipSetDevice(c->device));
-  const int64_t tx = tiles_x_of(c), ntiles = tiles_of_rank(tx * tiles_y_of(c), rank, world);
-  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, d_minmax);
-  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 32, c->stream));
-  if (ntiles == 0) return RTGPU_OK;
+namespace {
+
+// One chunk of tiles, first half: primary rays, then nearest-hit walk and hit kernel level by level
+// (raytrace.c:170-204); with planar lights also the number of shaded hits in every node's subtree.
+int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
+  const int n0 = nt_chunk * kTilePixels;
+  const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
+  const int64_t tx = tiles_x_of(c);
+  HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream));
+  {
+    Span sp(c, W_PRIMARY);
+    hipLaunchKernelGGL(k_primary, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, c->cam, c->grid, (int)t0, nt_chunk, rank, world,
+                       (int)tx, c->d_rays[0], c->d_ctl);
+  }
+  for (int L = 0; L < c->levels; L++) {
+    const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+    {
+      Span sp(c, W_NEAREST);
+      if (c->opt_count)
+        hipLaunchKernelGGL(k_nearest<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
+      else
+        hipLaunchKernelGGL(k_nearest<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
+    }
+    {
+      Span sp(c, W_HIT);
+      const bool spawn = L + 1 < c->levels;
+      hipLaunchKernelGGL(k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
+                         c->d_nodes, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
+                         spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn);
+    }
+  }
+  if (c->npl > 0) {
+    for (int L = c->levels - 1; L >= 0; L--) {
+      const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+      hipLaunchKernelGGL(k_subtree_hits, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_ctl, L, (int)c->base[L]);
+    }
+  }
+  return RTGPU_OK;
+}
+
+// Planar lights: the rand() replay rank of every shaded hit (one chunk = this rank's whole share of the image).
+// sizes: the level-0 subtree sizes of every rank (per_rank entries each), or this rank's own for world = 1;
+// total_hits: shaded hits of the whole frame if known, else -1 (world = 1: read back from the device).
+int chunk_ranks(rtgpu_ctx *c, int n0, const int32_t *sizes, int64_t per_rank, int rank, int world, int64_t total_hits) {
+  hipLaunchKernelGGL(k_tree_starts, dim3(1), dim3(1024), 0, c->stream, c->cam.sw, c->cam.sh, (int)tiles_x_of(c), sizes, (long long)per_rank,
+                     world, rank, c->d_rank);
+  for (int L = 0; L < c->levels; L++) {
+    const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+    hipLaunchKernelGGL(k_assign_ranks, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_rank, c->d_ctl, L, (int)c->base[L]);
+  }
+  if (c->fan > 0) {
+    // secondary hits draw random numbers too: the table must cover every shaded hit of the frame (a host sync,
+    // only for planar lights together with reflective or transparent surfaces)
+    unsigned long long shaded = (unsigned long long)(total_hits > 0 ? total_hits : 0);
+    if (total_hits < 0) {
+      HIPCHK(c, hipMemcpyAsync(&shaded, &c->d_ctl->stat[kShaded], sizeof shaded, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    int rc = ensure_rand(c, (size_t)shaded * c->npl * kPlanarSamples * 2);
+    if (rc) return rc;
+  }
+  return RTGPU_OK;
+}
+
+// Second half: shadow walks, colours deepest level first, colour range, statistics.
+int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d_ids, float *d_minmax) {
+  const int n0 = nt_chunk * kTilePixels;
+  const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
+  if (c->shade.nslots > 0) {
+    for (int L = 0; L < c->levels; L++) {
+      Span sp(c, W_SHADOW);
+      const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
+      if (c->opt_count)
+        hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+      else
+        hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+    }
+  }
+  for (int L = c->levels - 1; L >= 0; L--) {
+    Span sp(c, W_ACCUM);
+    const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->shade, c->d_rays[L], c->d_nodes,
+                       c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels);
+  }
+  {
+    Span sp(c, W_MINMAX);
+    int blocks = (n0 + 255) / 256;
+    if (blocks > kPartialBlocks) blocks = kPartialBlocks;
+    hipLaunchKernelGGL(k_minmax_partial, dim3(blocks), dim3(256), 0, c->stream, c->d_nodes, c->d_colors, n0, c->d_partial);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, blocks, d_minmax);
+  }
+  hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, c->stream, c->d_ctl, c->d_totals);
+  return RTGPU_OK;
+}
+
+// Tiles per chunk for this rank's share, and the queues for it.
+int plan_chunks(rtgpu_ctx *c, int64_t ntiles, bool whole, int64_t *chunk_out) {
   size_t per_tile = bytes_per_tile(c);
   int64_t chunk = (int64_t)(c->chunk_bytes / (int64_t)per_tile);
   if (chunk < 1) chunk = 1;
   if (chunk > ntiles) chunk = ntiles;
-  if (c->npl > 0 && chunk < ntiles)
-    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights need the whole image in one chunk; raise chunk_bytes");
+  if (whole && chunk < ntiles)
+    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights need this rank's whole share of the image in one chunk; raise chunk_bytes");
   if ((int64_t)chunk * kTilePixels * (c->fan > 1 ? 16 : 1) > 0x7fffffffll) chunk = 0x7fffffffll / (kTilePixels * (c->fan > 1 ? 16 : 1));
-  int rc = ensure_chunk(c, (size_t)chunk);
+  *chunk_out = chunk;
+  return ensure_chunk(c, (size_t)chunk);
+}
+
+}  // namespace
+
+int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax) {
+  if (!c || !d_rgb || !d_ids || !d_minmax || world <= 0 || rank < 0 || rank >= world) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
+  if (c->npl > 0 && world != 1)
+    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights on several GPUs: rtgpu_render_trace, exchange of rtgpu_hit_counts, rtgpu_render_shade");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t ntiles = tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
+  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, d_minmax);
+  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 32, c->stream));
+  c->split_tiles = -1;
+  if (ntiles == 0) return RTGPU_OK;
+  int64_t chunk = 0;
+  int rc = plan_chunks(c, ntiles, c->npl > 0, &chunk);
   if (rc) return rc;
   c->grid.slack = c->filter ? 0.0f : INFINITY;
-  const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
   for (int64_t t0 = 0; t0 < ntiles; t0 += chunk) {
     const int nt_chunk = (int)((ntiles - t0) < chunk ? (ntiles - t0) : chunk);
-    const int n0 = nt_chunk * kTilePixels;
-    HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream));
-    {
-      Span sp(c, W_PRIMARY);
-      hipLaunchKernelGGL(k_primary, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, c->cam, c->grid, (int)t0, nt_chunk, rank, world,
-                         (int)tx, c->d_rays[0], c->d_ctl);
-    }
-    for (int L = 0; L < c->levels; L++) {
-      const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-      {
-        Span sp(c, W_NEAREST);
-        if (c->opt_count)
-          hipLaunchKernelGGL(k_nearest<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
-        else
-          hipLaunchKernelGGL(k_nearest<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
-      }
-      {
-        Span sp(c, W_HIT);
-        const bool spawn = L + 1 < c->levels;
-        hipLaunchKernelGGL(k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
-                           c->d_nodes, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
-                           spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn);
-      }
-    }
-    if (c->npl > 0) {
-      // rand() replay order of the shaded hits (one chunk = the whole image, checked above)
-      for (int L = c->levels - 1; L >= 0; L--) {
-        const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-        hipLaunchKernelGGL(k_subtree_hits, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_ctl, L, (int)c->base[L]);
-      }
-      hipLaunchKernelGGL(k_tree_starts, dim3(1), dim3(1024), 0, c->stream, c->cam.sw, c->cam.sh, (int)tx, c->d_size, c->d_rank);
-      for (int L = 0; L < c->levels; L++) {
-        const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-        hipLaunchKernelGGL(k_assign_ranks, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_rank, c->d_ctl, L, (int)c->base[L]);
-      }
-      if (c->fan > 0) {
-        // secondary hits draw random numbers too: the table must cover every shaded hit of the frame (a host sync,
-        // only for planar lights together with reflective or transparent surfaces)
-        unsigned long long shaded = 0;
-        HIPCHK(c, hipMemcpyAsync(&shaded, &c->d_ctl->stat[kShaded], sizeof shaded, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if ((rc = ensure_rand(c, (size_t)shaded * c->npl * kPlanarSamples * 2))) return rc;
-      }
-    }
-    if (c->shade.nslots > 0) {
-      for (int L = 0; L < c->levels; L++) {
-        Span sp(c, W_SHADOW);
-        const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
-        if (c->opt_count)
-          hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
-        else
-          hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
-      }
-    }
-    for (int L = c->levels - 1; L >= 0; L--) {
-      Span sp(c, W_ACCUM);
-      const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-      hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->shade, c->d_rays[L], c->d_nodes,
-                         c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels);
-    }
-    {
-      Span sp(c, W_MINMAX);
-      int blocks = (n0 + 255) / 256;
-      if (blocks > kPartialBlocks) blocks = kPartialBlocks;
-      hipLaunchKernelGGL(k_minmax_partial, dim3(blocks), dim3(256), 0, c->stream, c->d_nodes, c->d_colors, n0, c->d_partial);
-      hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, blocks, d_minmax);
-    }
-    hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, c->stream, c->d_ctl, c->d_totals);
+    if ((rc = chunk_trace(c, t0, nt_chunk, rank, world))) return rc;
+    if (c->npl > 0 && (rc = chunk_ranks(c, nt_chunk * kTilePixels, c->d_size, 0, 0, 1, -1))) return rc;
+    if ((rc = chunk_shade(c, t0, nt_chunk, d_rgb, d_ids, d_minmax))) return rc;
   }
+  HIPCHK(c, hipGetLastError());
+  return RTGPU_OK;
+}
+
+int rtgpu_render_trace(rtgpu_ctx *c, int rank, int world) {
+  if (!c || world <= 0 || rank < 0 || rank >= world) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t ntiles = tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
+  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 32, c->stream));
+  c->split_tiles = -1;
+  if (ntiles == 0) { c->split_tiles = 0; c->split_rank = rank; c->split_world = world; return RTGPU_OK; }
+  int64_t chunk = 0;
+  int rc = plan_chunks(c, ntiles, true, &chunk);
+  if (rc) return rc;
+  c->grid.slack = c->filter ? 0.0f : INFINITY;
+  if ((rc = chunk_trace(c, 0, (int)ntiles, rank, world))) return rc;
+  HIPCHK(c, hipGetLastError());
+  c->split_tiles = ntiles; c->split_rank = rank; c->split_world = world;
+  return RTGPU_OK;
+}
+
+int rtgpu_hit_counts(rtgpu_ctx *c, int32_t *d_counts) {
+  if (!c || !d_counts) return RTGPU_E_INVALID_PARAM;
+  if (c->split_tiles < 0) return fail(c, RTGPU_E_STATE, "rtgpu_render_trace has not been called for this frame");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->split_tiles == 0) return RTGPU_OK;
+  const size_t n = (size_t)c->split_tiles * kTilePixels;
+  if (c->npl > 0) HIPCHK(c, hipMemcpyAsync(d_counts, c->d_size, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, c->stream));
+  else HIPCHK(c, hipMemsetAsync(d_counts, 0, sizeof(int32_t) * n, c->stream));
+  return RTGPU_OK;
+}
+
+int rtgpu_render_shade(rtgpu_ctx *c, const int32_t *d_all_counts, int64_t per_rank, int64_t total_hits, float *d_rgb, int32_t *d_ids,
+                       float *d_minmax) {
+  if (!c || !d_rgb || !d_ids || !d_minmax) return RTGPU_E_INVALID_PARAM;
+  if (c->split_tiles < 0) return fail(c, RTGPU_E_STATE, "rtgpu_render_trace has not been called for this frame");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, d_minmax);
+  const int64_t ntiles = c->split_tiles;
+  c->split_tiles = -1;
+  if (ntiles == 0) return RTGPU_OK;
+  int rc;
+  if (c->npl > 0) {
+    if (c->split_world > 1 && (!d_all_counts || per_rank < ntiles * kTilePixels || total_hits < 0))
+      return fail(c, RTGPU_E_INVALID_PARAM, "planar lights on several GPUs need every rank's hit counts and their sum");
+    if (c->split_world > 1) rc = chunk_ranks(c, (int)ntiles * kTilePixels, d_all_counts, per_rank, c->split_rank, c->split_world, total_hits);
+    else rc = chunk_ranks(c, (int)ntiles * kTilePixels, c->d_size, 0, 0, 1, -1);
+    if (rc) return rc;
+  }
+  if ((rc = chunk_shade(c, 0, (int)ntiles, d_rgb, d_ids, d_minmax))) return rc;
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
 }

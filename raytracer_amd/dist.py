@@ -2,7 +2,8 @@
 
 The frame is cut into 8x8-pixel tiles dealt round-robin to the ranks (cost per pixel varies by two
 orders of magnitude across an image, so fine interleaving is the load balancer).  Every rank holds the
-whole scene and traces only its tiles; there is exactly one exchange per frame:
+whole scene and traces only its tiles; there is exactly one exchange per frame (scenes with planar lights have
+one more, in the middle: the per-pixel hit counts that fix the order of the reference's rand() draws):
 
   1. all-reduce of the per-channel colour range (MAX over 6 floats: the negated minima and the maxima): the tone map divides by
      the GLOBAL range (src/raytrace.c:396-399, 433-435 of the reference), so it cannot start earlier;
@@ -37,6 +38,22 @@ def exchange_minmax(minmax, group=None):
     both = torch.cat([-minmax[:3], minmax[3:]])
     dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
     return torch.cat([-both[:3], both[3:]])
+
+
+def all_gather_counts(local, ntiles, group=None):
+    """Planar lights: every rank's per-pixel shaded-hit counts (tile-major, tile_count(rank)*64 each) on every rank.
+    Returns (tensor [world * per_rank], per_rank, total hits of the frame)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    per_rank = tile_count(ntiles, 0, world) * TILE_PIXELS
+    send = local
+    if local.numel() < per_rank:
+        send = torch.zeros(per_rank, dtype=local.dtype, device=local.device)
+        send[:local.numel()] = local
+    if world == 1:
+        return send, per_rank, int(send.sum().item())
+    out = torch.empty(per_rank * world, dtype=local.dtype, device=local.device)
+    dist.all_gather(list(out.split(per_rank)), send, group=group)
+    return out, per_rank, int(out.sum().item())
 
 
 def gather_tiles(local, ntiles, elems_per_pixel=1, dst=0, group=None):
@@ -110,6 +127,7 @@ class FrameRenderer:
         self.ids = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
         self.minmax = torch.zeros(6, dtype=torch.float32, device=dev)
         self.rgba = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+        self.counts = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
         self.image = torch.zeros(self.w * self.h, dtype=torch.int32, device=dev) if rank == 0 else None
         renderer.set_stream(torch.cuda.current_stream(dev))
 
@@ -118,7 +136,14 @@ class FrameRenderer:
         Returns the row-major RGBA8 image (int32 tensor, w*h) on rank 0."""
         r = self.r
         r.frame_begin()                                    # preprocess + grid build (replicated)
-        r.render(self.rgb, self.ids, self.minmax, self.rank, self.world)
+        if self.scene.npl > 0 and self.world > 1:
+            # planar lights draw rand() in pixel order: the ranks exchange their hit counts between the two halves
+            r.render_trace(self.rank, self.world)
+            r.hit_counts(self.counts)
+            every, per_rank, total = all_gather_counts(self.counts[:self.npix_local], self.ntiles, self.group)
+            r.render_shade(self.rgb, self.ids, self.minmax, every, per_rank, total)
+        else:
+            r.render(self.rgb, self.ids, self.minmax, self.rank, self.world)
         mm = exchange_minmax(self.minmax, self.group)      # exchange 1: 2 x 3 floats
         r.tonemap(self.rgb, self.npix_local, mm, self.scene.gamma, self.rgba)
         self.global_minmax = mm

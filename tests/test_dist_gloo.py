@@ -37,6 +37,15 @@ def _worker(rank, world, port, w, h, rgb, ids, out_q):
         px = mine_rgb[inside]
         local = np.concatenate([px.min(0), px.max(0)]).astype(np.float32) if px.size else np.array([3.4e38] * 3 + [1.17e-38] * 3, np.float32)
         mm = D.exchange_minmax(torch.from_numpy(local))
+        # planar lights: every rank ends up with every rank's per-pixel counts, each rank's block per_rank long
+        counts = ((mine_ids >= 0) & inside).reshape(-1).astype(np.int32)  # (tiles are padded with zeros outside the image)
+        every, per_rank, total = D.all_gather_counts(torch.from_numpy(counts), ntiles)
+        assert per_rank == D.tile_count(ntiles, 0, world) * 64 and every.numel() == world * per_rank
+        assert total == int((ids >= 0).sum())
+        for r in range(world):
+            want = ((D.split_tiles_reference(ids, r, world) >= 0) & D.split_tiles_reference(np.ones((h, w), bool), r, world)).reshape(-1).astype(np.int32)
+            got = every[r * per_rank:(r + 1) * per_rank].numpy()
+            assert np.array_equal(got[:want.size], want) and not got[want.size:].any()
         g_ids = D.gather_tiles(torch.from_numpy(mine_ids.reshape(-1).copy()), ntiles, 1)
         g_rgb = D.gather_tiles(torch.from_numpy(mine_rgb.reshape(-1).copy()), ntiles, 3)
         if rank == 0:

@@ -124,7 +124,7 @@ def test_frames_are_idempotent_and_independent_of_the_persistent_grid_size(rende
         assert np.array_equal(a["rgb"].view(np.uint32), other["rgb"].view(np.uint32))
 
 
-def test_planar_lights_refuse_more_than_one_rank(renderer):
+def test_planar_lights_refuse_more_than_one_rank_in_one_call(renderer):
     import torch
     scene = rt.Scene(os.path.join(ROOT, "scenes/s2/s2"), width=32, height=24)
     renderer.upload(scene)
@@ -135,6 +135,49 @@ def test_planar_lights_refuse_more_than_one_rank(renderer):
     with pytest.raises(rt.RtgpuError) as e:
         renderer.render(rgb, ids, mm, 0, 2)
     assert e.value.code == 102
+
+
+@pytest.mark.parametrize("over,world", [({}, 2), ({}, 3), ({"atr": "scenes/pokoj/s2.atr"}, 2)], ids=["s2_w2", "s2_w3", "s2_glass_w2"])
+def test_planar_lights_on_several_ranks_draw_rand_in_the_reference_order(renderer, over, world):
+    """trace / exchange of hit counts / shade with `world` contexts on one GPU: the reassembled frame equals the
+    single-rank frame bit for bit (which equals the reference: test_gpu_parity), secondary rays included."""
+    import torch
+    from raytracer_amd import dist as D
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    w, h = 120, 90
+    scene = rt.Scene(os.path.join(ROOT, "scenes/s2/s2"), width=w, height=h, **over)
+    renderer.upload(scene)
+    renderer.frame_begin()
+    whole = renderer.render_host()
+    ntiles = D.tiles_of(w, h)
+    ranks = [rt.Renderer(0) for _ in range(world)]
+    try:
+        counts = []
+        for k, r in enumerate(ranks):
+            r.upload(scene); r.frame_begin(); r.render_trace(k, world)
+            c = torch.zeros(r.tile_count(k, world) * 64, dtype=torch.int32, device="cuda")
+            r.hit_counts(c); r.sync()
+            counts.append(c)
+        per_rank = D.tile_count(ntiles, 0, world) * 64
+        every = torch.zeros(world * per_rank, dtype=torch.int32, device="cuda")
+        for k, c in enumerate(counts):
+            every[k * per_rank:k * per_rank + c.numel()] = c
+        total = int(every.sum().item())
+        rgbs, idss, mms = [], [], []
+        for k, r in enumerate(ranks):
+            n = r.tile_count(k, world) * 64
+            rgb = torch.zeros(n * 3, device="cuda"); ids = torch.zeros(n, dtype=torch.int32, device="cuda"); mm = torch.zeros(6, device="cuda")
+            r.render_shade(rgb, ids, mm, every, per_rank, total); r.sync()
+            rgbs.append(rgb.cpu().numpy().reshape(-1, 3)); idss.append(ids.cpu().numpy()); mms.append(mm.cpu().numpy())
+        rgb = D.untile_reference(np.concatenate(rgbs), world, w, h)
+        ids = D.untile_reference(np.concatenate(idss), world, w, h)
+        assert np.array_equal(ids, whole["ids"])
+        assert np.array_equal(rgb.view(np.uint32), whole["rgb"].view(np.uint32))
+        mm = np.stack(mms)
+        assert np.array_equal(np.concatenate([mm[:, :3].min(0), mm[:, 3:].max(0)]), whole["minmax"])
+    finally:
+        for r in ranks:
+            r.close()
 
 
 @pytest.mark.parametrize("name", ["s3", "temple", "ulica", "test"])
