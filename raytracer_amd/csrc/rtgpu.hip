@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rtgpu.h"
@@ -33,6 +34,7 @@ struct rtgpu_ctx {
   bool opt_count = false, opt_timing = false;
   int64_t chunk_bytes = 8ll << 30;
   int waves_per_cu = 4 * RT_WAVES;  // what the walk kernels are compiled for (their register budget)
+  bool opt_pipeline = true;  // frame set-up on its own stream, into the set of buffers the previous frame does not use
   bool filter = true;        // staged triangle filter + batch culling (off: every listed triangle gets the exact test)
   // scene, host side
   bool have_scene = false, have_frame = false;
@@ -58,6 +60,22 @@ struct rtgpu_ctx {
   float lmax = 0.0f;         // longest triangle edge of the uploaded scene
   int64_t known_nrefs = -1;  // reference count of the uploaded scene's grid (it does not depend on the camera)
   int64_t known_nonempty = 0;  // and its number of non-empty cells
+  // Two sets of everything the trace kernels read of a frame's set-up (per-camera triangle data, grid), so that
+  // rtgpu_frame_begin can build the next frame's set on its own stream while the previous frame's kernels still
+  // run: the members above are the set in use, `alt` is the other one.  released[p]: the renders that read the set
+  // of parity p are enqueued up to here; built: the set just built is complete.
+  struct GridSet {
+    float *d_geom = nullptr, *d_aux = nullptr;
+    uint32_t *d_cell_start = nullptr, *d_hdr_start = nullptr, *d_occ = nullptr;
+    BatchHdr *d_hdrs = nullptr;
+    float4 *d_nrm = nullptr;
+    TriRec *d_recs = nullptr;
+    int32_t *d_refs = nullptr;
+  } alt;
+  hipStream_t build_stream = nullptr;
+  hipEvent_t ev_built = nullptr, ev_released[2] = {nullptr, nullptr};
+  bool released_valid[2] = {false, false};
+  int parity = 0;
   // a frame rendered in two halves (rtgpu_render_trace ... rtgpu_render_shade): tiles of the share, -1 = none pending
   int64_t split_tiles = -1;
   int split_rank = 0, split_world = 1;
@@ -110,16 +128,28 @@ void dev_free(T **p) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
-struct Span {
-  rtgpu_ctx *c; int what; hipEvent_t a = nullptr, b = nullptr;
-  Span(rtgpu_ctx *ctx, int w) : c(ctx), what(w) {
+void swap_grid_sets(rtgpu_ctx *c) {
+  std::swap(c->d_geom, c->alt.d_geom); std::swap(c->d_aux, c->alt.d_aux);
+  std::swap(c->d_cell_start, c->alt.d_cell_start); std::swap(c->d_hdr_start, c->alt.d_hdr_start); std::swap(c->d_occ, c->alt.d_occ);
+  std::swap(c->d_hdrs, c->alt.d_hdrs); std::swap(c->d_nrm, c->alt.d_nrm); std::swap(c->d_recs, c->alt.d_recs);
+  std::swap(c->d_refs, c->alt.d_refs);
+  c->parity ^= 1;
+}
+// The kernels that read the current set are enqueued up to here.
+void mark_released(rtgpu_ctx *c) {
+  if (hipEventRecord(c->ev_released[c->parity], c->stream) == hipSuccess) c->released_valid[c->parity] = true;
+}
+
+struct Span {  // HIP events around launches, on the stream the kernels go to
+  rtgpu_ctx *c; int what; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+  Span(rtgpu_ctx *ctx, int w, hipStream_t stream = nullptr) : c(ctx), what(w), st(stream ? stream : ctx->stream) {
     if (c->opt_timing) {
       (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-      (void)hipEventRecord(a, c->stream);
+      (void)hipEventRecord(a, st);
     }
   }
   ~Span() {
-    if (c->opt_timing) { (void)hipEventRecord(b, c->stream); c->spans.push_back({a, b, what}); }
+    if (c->opt_timing) { (void)hipEventRecord(b, st); c->spans.push_back({a, b, what}); }
   }
 };
 
@@ -247,6 +277,13 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
     return RTGPU_E_NO_DEVICE;
   }
   c->stream = c->own_stream;
+  if (hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_built, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_released[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_released[1], hipEventDisableTiming) != hipSuccess) {
+    rtgpu_destroy(c);
+    return RTGPU_E_NO_DEVICE;
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
   if (hipMalloc((void **)&c->d_ctl, sizeof(Ctl)) != hipSuccess ||
@@ -265,7 +302,13 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->build_stream) (void)hipStreamSynchronize(c->build_stream);
   resolve_spans(c);
+  dev_free(&c->alt.d_geom); dev_free(&c->alt.d_aux); dev_free(&c->alt.d_cell_start); dev_free(&c->alt.d_hdr_start); dev_free(&c->alt.d_occ);
+  dev_free(&c->alt.d_hdrs); dev_free(&c->alt.d_nrm); dev_free(&c->alt.d_recs); dev_free(&c->alt.d_refs);
+  if (c->ev_built) (void)hipEventDestroy(c->ev_built);
+  for (int k = 0; k < 2; k++) if (c->ev_released[k]) (void)hipEventDestroy(c->ev_released[k]);
+  if (c->build_stream) (void)hipStreamDestroy(c->build_stream);
   dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs); dev_free(&c->d_recs_unsorted);
@@ -291,6 +334,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
+  else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = value == 0 ? 4 * RT_WAVES : (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
   return RTGPU_OK;
@@ -350,8 +394,10 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   if ((rc = dev_alloc(c, &c->d_verts, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->d_geom, (size_t)s->nt * 9)) ||
       (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_filt, (size_t)s->nt * kRecFloats)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
       (rc = dev_alloc(c, &c->d_box, (size_t)s->nt * 6 + ((size_t)s->nt + 63) / 64 * 6)) || (rc = dev_alloc(c, &c->d_surf, (size_t)s->ns)) ||
-      (rc = dev_alloc(c, &c->d_lights, (size_t)s->nl)) || (rc = dev_alloc(c, &c->d_planar, (size_t)s->npl)))
+      (rc = dev_alloc(c, &c->d_lights, (size_t)s->nl)) || (rc = dev_alloc(c, &c->d_planar, (size_t)s->npl)) ||
+      (rc = dev_alloc(c, &c->alt.d_geom, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->alt.d_aux, (size_t)s->nt * 4)))
     return rc;
+  c->released_valid[0] = c->released_valid[1] = false;  // (hipFree in dev_alloc waited for everything in flight)
   static_assert(sizeof(rtgpu_surface) == sizeof(SurfaceD) && sizeof(rtgpu_light) == sizeof(LightD) &&
                     sizeof(rtgpu_planar_light) == sizeof(PlanarD) && sizeof(rtgpu_camera) == sizeof(CameraD),
                 "ABI structs and device structs share one layout");
@@ -409,24 +455,32 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   if ((size_t)ncells + 1 > c->cap_cells) {
     if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->d_nbatch, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_hdr_start, (size_t)ncells + 1)) ||
-        (rc = dev_alloc(c, &c->d_occ, (size_t)ncells / 32 + 1 + 8))) return rc;  // + the box of the non-empty cells
+        (rc = dev_alloc(c, &c->d_occ, (size_t)ncells / 32 + 1 + 8)) ||  // + the box of the non-empty cells
+        (rc = dev_alloc(c, &c->alt.d_cell_start, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->alt.d_hdr_start, (size_t)ncells + 1)) ||
+        (rc = dev_alloc(c, &c->alt.d_occ, (size_t)ncells / 32 + 1 + 8))) return rc;
     c->cap_cells = (size_t)ncells + 1;
   }
+  // The set-up of this frame goes into the set the previous frame does not use, on the build stream: it overlaps
+  // the previous frame's kernels (their tail, a few slow wavefronts, leaves most of the GPU idle).
+  const bool piped = c->opt_pipeline;
+  hipStream_t bs = piped ? c->build_stream : c->stream;
+  swap_grid_sets(c);
+  if (piped && c->released_valid[c->parity]) HIPCHK(c, hipStreamWaitEvent(bs, c->ev_released[c->parity], 0));
   GridP g;
   for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
   g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.occ = c->d_occ; g.occ_box = reinterpret_cast<const int32_t *>(c->d_occ + ((size_t)ncells / 32 + 1)); g.cell_hdrs = nullptr; g.cell_nrm = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
-    Span sp(c, W_PRE);
-    hipLaunchKernelGGL(k_preprocess, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, f3{cam->ob[0], cam->ob[1], cam->ob[2]}, c->d_sid, c->d_surf,
+    Span sp(c, W_PRE, bs);
+    hipLaunchKernelGGL(k_preprocess, dim3(tblocks), dim3(tb), 0, bs, c->nt, c->d_verts, f3{cam->ob[0], cam->ob[1], cam->ob[2]}, c->d_sid, c->d_surf,
                        c->d_geom, c->d_aux, c->d_filt);
   }
   uint32_t nrefs = 0;
   {
-    Span sp(c, W_GRID);
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), c->stream));
-    hipLaunchKernelGGL(k_tri_boxes, dim3(tblocks), dim3(tb), 0, c->stream, c->nt, c->d_verts, g, c->d_box, c->d_counts);
-    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(1024), 0, c->stream, ncells, nv[1], nv[2], c->d_counts, c->d_cell_start, c->d_hdr_start, c->d_nbatch, c->d_occ,
+    Span sp(c, W_GRID, bs);
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), bs));
+    hipLaunchKernelGGL(k_tri_boxes, dim3(tblocks), dim3(tb), 0, bs, c->nt, c->d_verts, g, c->d_box, c->d_counts);
+    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(1024), 0, bs, ncells, nv[1], nv[2], c->d_counts, c->d_cell_start, c->d_hdr_start, c->d_nbatch, c->d_occ,
                        reinterpret_cast<int32_t *>(c->d_occ + ((size_t)ncells / 32 + 1)));
     // The grid depends on the scene and its lights only, so the numbers of references and of non-empty cells are
     // read back (a host sync) for the first frame of a scene and reused afterwards; the lists themselves are
@@ -436,33 +490,38 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
       nrefs = (uint32_t)c->known_nrefs;
       nonempty = (uint32_t)c->known_nonempty;
     } else {
-      HIPCHK(c, hipMemcpyAsync(&nrefs, c->d_cell_start + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(&nonempty, c->d_nbatch + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpyAsync(&nrefs, c->d_cell_start + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
+      HIPCHK(c, hipMemcpyAsync(&nonempty, c->d_nbatch + ncells, sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
+      HIPCHK(c, hipStreamSynchronize(bs));
       c->known_nrefs = nrefs;
       c->known_nonempty = nonempty;
       for (int k = 0; k < 3; k++) c->known_nv[k] = nv[k];
     }
     if ((size_t)nrefs > c->cap_refs) {
       if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_recs_unsorted, (size_t)nrefs)) ||
-          (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs)) ||
-          (rc = dev_alloc(c, &c->d_nrm, (size_t)nrefs))) return rc;
+          (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_nrm, (size_t)nrefs)) ||
+          (rc = dev_alloc(c, &c->alt.d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->alt.d_refs, (size_t)nrefs)) ||
+          (rc = dev_alloc(c, &c->alt.d_nrm, (size_t)nrefs))) return rc;
       c->cap_refs = nrefs;
     }
     // one header per kBatch records of a cell: at most nrefs / kBatch full batches plus one partial batch per non-empty cell
     const size_t nhdrs = (size_t)nrefs / kBatch + ((size_t)nrefs < (size_t)ncells ? (size_t)nrefs : (size_t)ncells) + 1;
     if (nhdrs > c->cap_hdrs) {
-      if ((rc = dev_alloc(c, &c->d_hdrs, nhdrs))) return rc;
+      if ((rc = dev_alloc(c, &c->d_hdrs, nhdrs)) || (rc = dev_alloc(c, &c->alt.d_hdrs, nhdrs))) return rc;
       c->cap_hdrs = nhdrs;
     }
     g.cell_tris = c->d_recs;
     g.cell_hdrs = c->d_hdrs;
     g.cell_nrm = reinterpret_cast<const float *>(c->d_nrm);
     if (nonempty > 0) {  // d_nbatch holds the list of the non-empty cells, its length at [ncells]
-      hipLaunchKernelGGL(k_grid_fill, dim3((nonempty + 3) / 4), dim3(256), 0, c->stream, c->nt, g, c->d_nbatch, c->d_box, c->d_recs_unsorted, c->d_refs);
-      hipLaunchKernelGGL(k_grid_sort, dim3(nonempty), dim3(kSortThreads), 0, c->stream, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs, c->d_nrm);
-      hipLaunchKernelGGL(k_grid_bounds, dim3(nonempty), dim3(256), 0, c->stream, g, c->d_nbatch, c->d_hdrs);
+      hipLaunchKernelGGL(k_grid_fill, dim3((nonempty + 3) / 4), dim3(256), 0, bs, c->nt, g, c->d_nbatch, c->d_box, c->d_recs_unsorted, c->d_refs);
+      hipLaunchKernelGGL(k_grid_sort, dim3(nonempty), dim3(kSortThreads), 0, bs, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs, c->d_nrm);
+      hipLaunchKernelGGL(k_grid_bounds, dim3(nonempty), dim3(256), 0, bs, g, c->d_nbatch, c->d_hdrs);
     }
+  }
+  if (piped) {
+    HIPCHK(c, hipEventRecord(c->ev_built, bs));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_built, 0));
   }
   HIPCHK(c, hipGetLastError());
   c->grid = g;
@@ -625,6 +684,7 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
     if (c->npl > 0 && (rc = chunk_ranks(c, nt_chunk * kTilePixels, c->d_size, 0, 0, 1, -1))) return rc;
     if ((rc = chunk_shade(c, t0, nt_chunk, d_rgb, d_ids, d_minmax))) return rc;
   }
+  mark_released(c);
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
 }
@@ -642,6 +702,7 @@ int rtgpu_render_trace(rtgpu_ctx *c, int rank, int world) {
   if (rc) return rc;
   c->grid.slack = c->filter ? 0.0f : INFINITY;
   if ((rc = chunk_trace(c, 0, (int)ntiles, rank, world))) return rc;
+  mark_released(c);
   HIPCHK(c, hipGetLastError());
   c->split_tiles = ntiles; c->split_rank = rank; c->split_world = world;
   return RTGPU_OK;
@@ -676,6 +737,7 @@ int rtgpu_render_shade(rtgpu_ctx *c, const int32_t *d_all_counts, int64_t per_ra
     if (rc) return rc;
   }
   if ((rc = chunk_shade(c, 0, (int)ntiles, d_rgb, d_ids, d_minmax))) return rc;
+  mark_released(c);
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
 }
