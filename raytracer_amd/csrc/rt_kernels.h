@@ -2,7 +2,7 @@
 //
 // Frame set-up          k_preprocess, k_tri_boxes, k_grid_offsets, k_grid_fill
 // Pixel loop (a chunk)  k_primary -> [k_nearest -> k_hit] per recursion level -> k_shadow per level
-//                       -> k_accumulate per level, deepest first -> k_minmax_*
+//                       -> k_accumulate per level, deepest first (level 0 folds the colour range of its blocks) -> k_minmax_final
 // After the exchange    k_tonemap, k_untile
 #pragma once
 #include "rt_math.h"
@@ -1532,6 +1532,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   }
 }
 
+RT_D void mm_fold(float *mn, float *mx, const float *omn, const float *omx) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (omx[k] > mx[k]) mx[k] = omx[k];
+    if (omn[k] < mn[k]) mn[k] = omn[k];
+  }
+}
+
 // One light's contribution (raytrace.c:217-235 / 271-289).
 RT_D f3 light_term(const SurfaceD &sf, f3 norm, f3 r, f3 rnew, f3 onew, f3 lpos, float lflux, f3 lcol, f3 nc,
                    float ts, float distmod) {
@@ -1557,12 +1565,14 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
                                                     const float *__restrict__ ts_in, const int32_t *__restrict__ rand_rank,
                                                     float *__restrict__ colors, Ctl *__restrict__ ctl, int level,
                                                     int node_base, float *__restrict__ fb_rgb, int32_t *__restrict__ fb_ids,
-                                                    long long fb_base) {
+                                                    long long fb_base, float *__restrict__ partial) {
   const int n = ctl->count[level];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  const int gidx = node_base + idx;
-  const Node nd = nodes[gidx];
+  const bool valid = idx < n;
+  if (!valid && (level != 0 || partial == nullptr)) return;  // (level 0 folds its colour range block by block below)
+  const int gidx = node_base + (valid ? idx : 0);
+  Node nd = nodes[gidx];
+  if (!valid) nd.tri = -2;
   f3 res = mk3(0.0f, 0.0f, 0.0f);
   if (nd.tri >= 0) {
     const SurfaceD sf = sp.surf[sp.tri_sid[nd.tri]];
@@ -1603,11 +1613,35 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
       }
     }
   }
-  colors[4ll * gidx] = res.x; colors[4ll * gidx + 1] = res.y; colors[4ll * gidx + 2] = res.z;
-  if (level == 0) {
-    long long p = fb_base + idx;
-    fb_rgb[3 * p] = res.x; fb_rgb[3 * p + 1] = res.y; fb_rgb[3 * p + 2] = res.z;
-    fb_ids[p] = nd.tri >= 0 ? nd.tri : -1;
+  if (valid) {
+    colors[4ll * gidx] = res.x; colors[4ll * gidx + 1] = res.y; colors[4ll * gidx + 2] = res.z;
+    if (level == 0) {
+      long long p = fb_base + idx;
+      fb_rgb[3 * p] = res.x; fb_rgb[3 * p + 1] = res.y; fb_rgb[3 * p + 2] = res.z;
+      fb_ids[p] = nd.tri >= 0 ? nd.tri : -1;
+    }
+  }
+  if (level == 0 && partial != nullptr) {
+    // per-channel min/max over the traced pixels of this block (raytrace.c:396-399): partial[blockIdx.x][6]
+    __shared__ float sm[4][6];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
+    if (nd.tri >= -1) {
+      const float c[3] = {res.x, res.y, res.z};
+      mm_fold(mn, mx, c, c);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      float omn[3], omx[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { omn[k] = __shfl_down(mn[k], off); omx[k] = __shfl_down(mx[k], off); }
+      mm_fold(mn, mx, omn, omx);
+    }
+    const int wid = threadIdx.x >> 6;
+    if (lane_id() == 0) { for (int k = 0; k < 3; k++) { sm[wid][k] = mn[k]; sm[wid][3 + k] = mx[k]; } }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int wv = 1; wv < 4; wv++) mm_fold(mn, mx, &sm[wv][0], &sm[wv][3]);
+      for (int k = 0; k < 3; k++) { partial[blockIdx.x * 6 + k] = mn[k]; partial[blockIdx.x * 6 + 3 + k] = mx[k]; }
+    }
   }
 }
 
@@ -1615,37 +1649,6 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
 // Per-channel min/max over the traced pixels of a chunk (raytrace.c:396-399; NaN never wins because
 // the comparisons are the reference's `>` and `<`).  Pixels whose ray never entered the grid do not
 // take part.  partial: [blocks][6]; k_minmax_final folds partials into the running d_minmax.
-RT_D void mm_fold(float *mn, float *mx, const float *omn, const float *omx) {
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    if (omx[k] > mx[k]) mx[k] = omx[k];
-    if (omn[k] < mn[k]) mn[k] = omn[k];
-  }
-}
-__global__ void __launch_bounds__(256) k_minmax_partial(const Node *__restrict__ nodes, const float *__restrict__ colors,
-                                                        int n, float *__restrict__ partial) {
-  __shared__ float sm[4][6];
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-    if (nodes[idx].tri >= -1) {
-      float c[3] = {colors[4ll * idx], colors[4ll * idx + 1], colors[4ll * idx + 2]};
-      mm_fold(mn, mx, c, c);
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    float omn[3], omx[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { omn[k] = __shfl_down(mn[k], off); omx[k] = __shfl_down(mx[k], off); }
-    mm_fold(mn, mx, omn, omx);
-  }
-  const int lane = lane_id(), wid = threadIdx.x >> 6;
-  if (lane == 0) { for (int k = 0; k < 3; k++) { sm[wid][k] = mn[k]; sm[wid][3 + k] = mx[k]; } }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int wv = 1; wv < 4; wv++) mm_fold(mn, mx, &sm[wv][0], &sm[wv][3]);
-    for (int k = 0; k < 3; k++) { partial[blockIdx.x * 6 + k] = mn[k]; partial[blockIdx.x * 6 + 3 + k] = mx[k]; }
-  }
-}
 __global__ void __launch_bounds__(256) k_minmax_final(const float *__restrict__ partial, int nblocks, float *__restrict__ minmax) {
   __shared__ float sm[4][6];
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};

@@ -215,6 +215,7 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
   if ((rc = dev_alloc(c, &c->d_nodes, total))) return rc;
   if ((rc = dev_alloc(c, &c->d_colors, total * 4))) return rc;
   if ((rc = dev_alloc(c, &c->d_ts, total * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)))) return rc;
+  if ((rc = dev_alloc(c, &c->d_partial, (tiles * kTilePixels + 255) / 256 * 6))) return rc;  // colour range per block of level 0
   const size_t nrank = c->npl > 0 ? total : 1;
   if ((rc = dev_alloc(c, &c->d_rank, nrank)) || (rc = dev_alloc(c, &c->d_size, nrank))) return rc;
   c->chunk_tiles_cap = tiles;
@@ -635,14 +636,12 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
     Span sp(c, W_ACCUM);
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->shade, c->d_rays[L], c->d_nodes,
-                       c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels);
+                       c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
+                       L == 0 ? c->d_partial : nullptr);  // level 0 (the last one) also folds the colour range of its blocks
   }
   {
     Span sp(c, W_MINMAX);
-    int blocks = (n0 + 255) / 256;
-    if (blocks > kPartialBlocks) blocks = kPartialBlocks;
-    hipLaunchKernelGGL(k_minmax_partial, dim3(blocks), dim3(256), 0, c->stream, c->d_nodes, c->d_colors, n0, c->d_partial);
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, blocks, d_minmax);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, (n0 + 255) / 256, d_minmax);
   }
   hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, c->stream, c->d_ctl, c->d_totals);
   return RTGPU_OK;
