@@ -66,11 +66,28 @@ RT_D float row_minmax16(float x) {
   if (WIDTH == 16) x = dpp_minmax<0x118, 0xf, MAX>(x);  // row_shr:8
   return x;  // WIDTH 8: lanes 7 and 15 of a row hold the result of their half
 }
+RT_D float wave_max(float x);
+// The lane whose walk has made the least progress (smallest entry parameter of its current cell) among the lanes
+// of mask m: the rays of a wavefront cross cell boundaries at slightly different steps, and letting the stragglers
+// go first brings them into the cells where the others wait, so that a cell is visited by one large group instead
+// of several small ones.
+RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, float tz);
 RT_D float wave_max(float x) {
   x = row_minmax16<true>(x);
   x = dpp_minmax<0x142, 0xa, true>(x);  // row_bcast:15 into rows 1 and 3
   x = dpp_minmax<0x143, 0xc, true>(x);  // row_bcast:31 into rows 2 and 3
   return lane_bcast(x, 63);
+}
+
+RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, float tz) {
+#ifdef RT_FIRST_LANE_LEADS
+  return __ffsll(m) - 1;
+#else
+  const float key = alive ? __builtin_fmaxf(tx, __builtin_fmaxf(ty, tz)) : INFINITY;
+  const float least = -wave_max(-key);
+  const unsigned long long who = __ballot(alive && key == least);
+  return __ffsll(who != 0 ? who : m) - 1;  // (a NaN key equals nothing: then the first lane of the mask)
+#endif
 }
 
 // The rays a wavefront walks through one cell, as a bundle around the leader's ray (direction axis, moment
@@ -1016,7 +1033,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
     for (;;) {
       const unsigned long long m = __ballot(alive);
       if (m == 0) break;
-      const int leader = __ffsll(m) - 1;
+      const int leader = least_advanced(m, alive, w.tx, w.ty, w.tz);
       const int cell = __builtin_amdgcn_readlane(w.cell, leader);
       const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
       const uint32_t hbeg = __builtin_amdgcn_readlane(myhbeg, leader);
@@ -1393,7 +1410,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     for (;;) {
       const unsigned long long m = __ballot(alive);
       if (m == 0) break;
-      const int leader = __ffsll(m) - 1;
+      const int leader = least_advanced(m, alive, w.tx, w.ty, w.tz);
       const int cell = __builtin_amdgcn_readlane(w.cell, leader);
       const uint32_t beg = __builtin_amdgcn_readlane(mybeg, leader), cnt = __builtin_amdgcn_readlane(mycnt, leader);
       const uint32_t hbeg = __builtin_amdgcn_readlane(myhbeg, leader);
