@@ -30,14 +30,25 @@ def tile_count(ntiles, rank, world):
     return (ntiles - rank + world - 1) // world if rank < ntiles else 0
 
 
+_sign_cache = {}
+
+
+def _signs(like):
+    key = (like.device, like.dtype)
+    if key not in _sign_cache:
+        _sign_cache[key] = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=like.dtype, device=like.device)
+    return _sign_cache[key]
+
+
 def exchange_minmax(minmax, group=None):
     """minmax: tensor [6] = min rgb, max rgb of this rank.  Returns the global range on every rank."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return minmax
     # one collective: MAX of (-min, max); negation is exact, so this is the MIN of the minima
-    both = torch.cat([-minmax[:3], minmax[3:]])
+    sign = _signs(minmax)
+    both = minmax * sign
     dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
-    return torch.cat([-both[:3], both[3:]])
+    return both * sign
 
 
 def all_gather_counts(local, ntiles, group=None):
