@@ -152,6 +152,22 @@ def main():
                 traffic = json.load(open(tfile)).get("k_" + fam, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what really bounds the kernel: instruction issue.  Wave-instructions and cycles of one launch from the SQ
+        # counters of the last profiled run (profiles/pmc.json); the machine's rate from tools/micro/issue_rate.hip.
+        issue = None
+        pfile = os.path.join(ROOT, "profiles", "pmc.json")
+        if os.path.exists(pfile):
+            try:
+                pm = json.load(open(pfile)).get("k_" + fam, {})
+                insts = sum(pm.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"))
+                cycles = pm.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
+                if insts > 0 and cycles > 0:
+                    cpi = cycles * 1024.0 / insts  # 256 CUs x 4 SIMDs
+                    issue = {"wave_instructions_per_launch": int(insts), "cycles_per_launch": int(cycles),
+                             "cycles_per_instruction_per_simd": round(cpi, 3), "machine_cycles_per_instruction": 2.1,
+                             "frac": round(2.1 / cpi, 3), "source": "profiles/pmc.json (rocprofv3 --pmc of an earlier run of this workload)"}
+            except Exception:
+                issue = None
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": round(rays_frame * args.steps / elapsed / 1e6, 3),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +188,7 @@ def main():
                          "executed_tests_frac": round(cnt[fam + "_lane_slots"] / T, 4) if T else None,
                          "note": "logical bytes (64 B/ray + 8 B/voxel + 40 B/listed triangle); the scene is cache-resident and "
                                  "batches of listed triangles are culled, so frac exceeds 1 without touching HBM; the kernel is "
-                                 "bound by instruction issue (see profiles/)"},
+                                 "bound by instruction issue (see profiles/)", "issue": issue},
         }
         def ratio(a, b):
             return round(a / b, 4) if b else None

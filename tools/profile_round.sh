@@ -13,5 +13,6 @@ timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/$
 (cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_trace -- python3 $ROOT/bench.py --no-cpu-baseline > $ROOT/gpurun_out/${TAG}_trace.log 2>&1) || { tail -5 gpurun_out/${TAG}_trace.log; exit 1; }
 bash tools/pmc.sh raytracer_amd/librtgpu.so $TAG || exit 1
 python3 tools/pmc_summary.py gpurun_out/pmc_${TAG}_1 gpurun_out/pmc_${TAG}_2 gpurun_out/pmc_${TAG}_3 > gpurun_out/${TAG}_pmc_sq_counters.txt
+cp profiles/pmc.json gpurun_out/pmc.json
 echo profile round $TAG done
 
