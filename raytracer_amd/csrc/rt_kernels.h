@@ -944,7 +944,12 @@ RT_D bool walk_to_occupied(const GridP &g, const uint32_t *occ_s, bool in_lds, f
 __global__ void __launch_bounds__(256) k_primary(CameraD cam, GridP g, int tile0, int ntiles, int rank, int world,
                                                  int tiles_x, Ray *__restrict__ rays, Ctl *__restrict__ ctl) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx == 0) ctl->count[0] = ntiles * kTilePixels;
+  if (blockIdx.x == 0) {  // also resets the chunk's control block: queue lengths, tickets, statistics
+    static_assert(sizeof(Ctl) % 4 == 0 && sizeof(Ctl) / 4 <= 256, "one thread per word of the control block");
+    if (threadIdx.x < sizeof(Ctl) / 4) reinterpret_cast<uint32_t *>(ctl)[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) ctl->count[0] = ntiles * kTilePixels;
+  }
   if (idx >= ntiles * kTilePixels) return;
   int lt = tile0 + (idx >> 6), slot = idx & 63;
   long long gt = (long long)lt * world + rank;
@@ -1666,8 +1671,16 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
 // Per-channel min/max over the traced pixels of a chunk (raytrace.c:396-399; NaN never wins because
 // the comparisons are the reference's `>` and `<`).  Pixels whose ray never entered the grid do not
 // take part.  partial: [blocks][6]; k_minmax_final folds partials into the running d_minmax.
-__global__ void __launch_bounds__(256) k_minmax_final(const float *__restrict__ partial, int nblocks, float *__restrict__ minmax) {
+// End of a chunk: folds the blocks' colour ranges into the running range and, if ctl is given, the chunk's statistics
+// and queue lengths into the frame totals (k_fold_stats).
+__global__ void __launch_bounds__(256) k_minmax_final(const float *__restrict__ partial, int nblocks, float *__restrict__ minmax,
+                                                      const Ctl *__restrict__ ctl = nullptr, unsigned long long *__restrict__ totals = nullptr) {
   __shared__ float sm[4][6];
+  if (ctl != nullptr) {
+    const int t = threadIdx.x;
+    if (t < kStatCount) totals[t] += ctl->stat[t];
+    else if (t < kStatCount + kMaxLevels) totals[t] += (unsigned long long)ctl->count[t - kStatCount];
+  }
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
   for (int b = threadIdx.x; b < nblocks; b += 256) mm_fold(mn, mx, partial + 6 * b, partial + 6 * b + 3);
   for (int off = 32; off > 0; off >>= 1) {
@@ -1684,6 +1697,12 @@ __global__ void __launch_bounds__(256) k_minmax_final(const float *__restrict__ 
     for (int wv = 0; wv < 4; wv++) mm_fold(fmn, fmx, sm[wv], sm[wv] + 3);
     for (int k = 0; k < 3; k++) { minmax[k] = fmn[k]; minmax[3 + k] = fmx[k]; }
   }
+}
+// Start of a frame: the running colour range and the frame's statistics.
+__global__ void k_frame_init(float *minmax, unsigned long long *totals) {
+  if (threadIdx.x < 3) minmax[threadIdx.x] = FLT_MAX;       // raytrace.c:318
+  else if (threadIdx.x < 6) minmax[threadIdx.x] = FLT_MIN;  // raytrace.c:319 (smallest positive normal, as written)
+  if (threadIdx.x < 32) totals[threadIdx.x] = 0ull;
 }
 __global__ void k_minmax_init(float *minmax) {
   if (threadIdx.x < 3) minmax[threadIdx.x] = FLT_MAX;       // raytrace.c:318

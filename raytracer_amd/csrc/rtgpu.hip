@@ -562,9 +562,8 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   const int n0 = nt_chunk * kTilePixels;
   const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
   const int64_t tx = tiles_x_of(c);
-  HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Ctl), c->stream));
   {
-    Span sp(c, W_PRIMARY);
+    Span sp(c, W_PRIMARY);  // (k_primary also resets the control block)
     hipLaunchKernelGGL(k_primary, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, c->cam, c->grid, (int)t0, nt_chunk, rank, world,
                        (int)tx, c->d_rays[0], c->d_ctl);
   }
@@ -641,9 +640,9 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   }
   {
     Span sp(c, W_MINMAX);
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, (n0 + 255) / 256, d_minmax);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, (n0 + 255) / 256, d_minmax,
+                       (const Ctl *)c->d_ctl, c->d_totals);  // also the chunk's statistics into the frame totals
   }
-  hipLaunchKernelGGL(k_fold_stats, dim3(1), dim3(64), 0, c->stream, c->d_ctl, c->d_totals);
   return RTGPU_OK;
 }
 
@@ -669,8 +668,7 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
     return fail(c, RTGPU_E_UNSUPPORTED, "planar lights on several GPUs: rtgpu_render_trace, exchange of rtgpu_hit_counts, rtgpu_render_shade");
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t ntiles = tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
-  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, d_minmax);
-  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 32, c->stream));
+  hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, d_minmax, c->d_totals);
   c->split_tiles = -1;
   if (ntiles == 0) return RTGPU_OK;
   int64_t chunk = 0;
