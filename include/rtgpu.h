@@ -129,6 +129,9 @@ void rtgpu_destroy(rtgpu_ctx *ctx);
  * instead of its own, so that rendering orders with the caller's collectives without host syncs.
  * NULL switches back to the context's own stream. */
 int rtgpu_set_stream(rtgpu_ctx *ctx, void *hip_stream);
+/* The same for the device's null stream (the legacy default stream, handle 0: what torch.cuda.current_stream() is
+ * unless the caller made another one current), which rtgpu_set_stream cannot name because NULL means "own". */
+int rtgpu_set_null_stream(rtgpu_ctx *ctx);
 
 /* Options: "count" (0/1) S/T counters, "timing" (0/1) per-kernel events, "chunk_bytes" (device
  * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default, 24), "pipeline" (default 1: rtgpu_frame_begin builds on its

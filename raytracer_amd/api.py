@@ -113,6 +113,7 @@ def gpu_lib():
         L.rtgpu_destroy.restype = None
         L.rtgpu_set_option.argtypes = [vp, C.c_char_p, i64]
         L.rtgpu_set_stream.argtypes = [vp, vp]
+        L.rtgpu_set_null_stream.argtypes = [vp]
         L.rtgpu_scene_upload.argtypes = [vp, C.POINTER(SceneDesc)]
         L.rtgpu_frame_begin.argtypes = [vp, C.POINTER(Camera)]
         L.rtgpu_grid_info_get.argtypes = [vp, C.POINTER(GridInfo)]
@@ -299,9 +300,13 @@ class Renderer:
         self._chk(self._L.rtgpu_set_option(self._h, name.encode(), int(value)), "rtgpu_set_option(%s)" % name)
 
     def set_stream(self, stream):
-        """stream: a torch.cuda.Stream, a raw hipStream_t handle, or None for the context's own stream."""
+        """stream: a torch.cuda.Stream, a raw hipStream_t handle, or None for the context's own stream.  A torch
+        stream whose handle is 0 is the device's null stream (torch's default): the context then enqueues there."""
         h = getattr(stream, "cuda_stream", stream)
-        self._chk(self._L.rtgpu_set_stream(self._h, C.c_void_p(h) if h else None), "rtgpu_set_stream")
+        if stream is not None and h == 0:
+            self._chk(self._L.rtgpu_set_null_stream(self._h), "rtgpu_set_null_stream")
+        else:
+            self._chk(self._L.rtgpu_set_stream(self._h, C.c_void_p(h) if h else None), "rtgpu_set_stream")
 
     def upload(self, scene):
         self._chk(self._L.rtgpu_scene_upload(self._h, C.byref(scene.desc)), "rtgpu_scene_upload")

@@ -302,7 +302,7 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
 void rtgpu_destroy(rtgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);
   if (c->build_stream) (void)hipStreamSynchronize(c->build_stream);
   resolve_spans(c);
   dev_free(&c->alt.d_geom); dev_free(&c->alt.d_aux); dev_free(&c->alt.d_cell_start); dev_free(&c->alt.d_hdr_start); dev_free(&c->alt.d_occ);
@@ -326,6 +326,14 @@ int rtgpu_set_stream(rtgpu_ctx *c, void *hip_stream) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return RTGPU_OK;
+}
+
+int rtgpu_set_null_stream(rtgpu_ctx *c) {
+  if (!c) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = nullptr;  // every launch, event and wait below takes the null stream as it is
   return RTGPU_OK;
 }
 

@@ -19,6 +19,8 @@ import torch.distributed as dist
 
 TILE = 8
 TILE_PIXELS = 64
+# Tests set this to run the collectives even in a group of one rank (RCCL then sees exactly the tensors it gets with more).
+FORCE_COLLECTIVES = False
 
 
 def tiles_of(width, height):
@@ -42,7 +44,7 @@ def _signs(like):
 
 def exchange_minmax(minmax, group=None):
     """minmax: tensor [6] = min rgb, max rgb of this rank.  Returns the global range on every rank."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES):
         return minmax
     # one collective: MAX of (-min, max); negation is exact, so this is the MIN of the minima
     sign = _signs(minmax)
@@ -60,7 +62,7 @@ def all_gather_counts(local, ntiles, group=None):
     if local.numel() < per_rank:
         send = torch.zeros(per_rank, dtype=local.dtype, device=local.device)
         send[:local.numel()] = local
-    if world == 1:
+    if world == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
         return send, per_rank, int(send.sum().item())
     out = torch.empty(per_rank * world, dtype=local.dtype, device=local.device)
     dist.all_gather(list(out.split(per_rank)), send, group=group)
@@ -76,7 +78,7 @@ def gather_tiles(local, ntiles, elems_per_pixel=1, dst=0, group=None):
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:
+    if world == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
         return local
     per_tile = TILE_PIXELS * elems_per_pixel
     most = tile_count(ntiles, 0, world) * per_tile
@@ -147,7 +149,7 @@ class FrameRenderer:
         Returns the row-major RGBA8 image (int32 tensor, w*h) on rank 0."""
         r = self.r
         r.frame_begin()                                    # preprocess + grid build (replicated)
-        if self.scene.npl > 0 and self.world > 1:
+        if self.scene.npl > 0 and (self.world > 1 or FORCE_COLLECTIVES):
             # planar lights draw rand() in pixel order: the ranks exchange their hit counts between the two halves
             r.render_trace(self.rank, self.world)
             r.hit_counts(self.counts)
