@@ -76,6 +76,12 @@ def main():
     ap.add_argument("--cpu-height", type=int, default=360)
     args = ap.parse_args()
 
+    # Libraries below write banners to the C-level stdout (RCCL prints its version when a communicator is made); the
+    # one JSON line is the only thing this program may print there, so stdout points to stderr until that line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import raytracer_amd as rt
@@ -89,7 +95,13 @@ def main():
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force = world == 1 and os.environ.get("RTGPU_BENCH_FORCE_COLLECTIVES") == "1"  # rehearsal of the N > 1 code on one GPU
+    if world > 1 or force:
+        if force:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            import raytracer_amd.dist as rdist
+            rdist.FORCE_COLLECTIVES = True
         dist.init_process_group("nccl", device_id=dev)
 
     scenes = {"temple": ("scenes/temple/temple", {}), "ulica": ("scenes/ulica/ulica", {}), "s3": ("scenes/s3/s3", {}),
@@ -205,8 +217,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(prefix, over, args.cpu_width, args.cpu_height)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 
