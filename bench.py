@@ -159,7 +159,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and world == 1:  # (the counters were collected on whole-frame launches)
             try:
                 traffic = json.load(open(tfile)).get("k_" + fam, {}).get("hbm_bytes_per_launch")
             except Exception:
@@ -168,7 +168,7 @@ def main():
         # counters of the last profiled run (profiles/pmc.json); the machine's rate from tools/micro/issue_rate.hip.
         issue = None
         pfile = os.path.join(ROOT, "profiles", "pmc.json")
-        if os.path.exists(pfile):
+        if os.path.exists(pfile) and world == 1:
             try:
                 pm = json.load(open(pfile)).get("k_" + fam, {})
                 insts = sum(pm.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"))
