@@ -151,6 +151,8 @@ def host_lib():
         vp = C.c_void_p
         L.rtSceneLoadAll.restype = vp
         L.rtSceneLoadAll.argtypes = [C.c_char_p] * 5 + [C.c_float] * 3
+        L.rtSceneLoadAllCached.restype = vp
+        L.rtSceneLoadAllCached.argtypes = [C.c_char_p] * 6 + [C.c_float] * 3
         L.rtSceneDestroy.argtypes = [C.POINTER(vp)]
         L.rtCameraLoad.restype = vp
         L.rtCameraLoad.argtypes = [C.c_char_p]
@@ -197,15 +199,16 @@ def save_bmp24(rgba, path):
 class Scene:
     """A scene loaded by the C host layer (same files and quirks as the reference's loaders)."""
 
-    def __init__(self, prefix, texture=False, width=None, height=None, gamma=2.5, epsilon=0.0, distmod=2.0, **over):
+    def __init__(self, prefix, texture=False, width=None, height=None, gamma=2.5, epsilon=0.0, distmod=2.0, geometry_cache=None, **over):
         """texture: False = brick texture off, True = on (needs textures/brickwall.bmp in the cwd, which is the
-        reference's on/off switch, src/preprocess.c:13), None = on iff that file can be loaded."""
+        reference's on/off switch, src/preprocess.c:13), None = on iff that file can be loaded.
+        geometry_cache: path of a binary cache of the geometry file (rtSceneLoadCached), or None."""
         H = host_lib()
         p = scene_paths(prefix, **over)
         enc = lambda s: s.encode() if s else None
         C.set_errno(0)
-        self._scene = H.rtSceneLoadAll(enc(p["brs"]), enc(p["lgt"]), enc(p["pnr"]), enc(p["atr"]), enc(p["cfg"]),
-                                       gamma, epsilon, distmod)
+        self._scene = H.rtSceneLoadAllCached(enc(p["brs"]), enc(geometry_cache), enc(p["lgt"]), enc(p["pnr"]), enc(p["atr"]), enc(p["cfg"]),
+                                             gamma, epsilon, distmod)
         if not self._scene:
             raise RuntimeError("cannot load scene %s" % prefix)
         self._cam = H.rtCameraLoad(enc(p["cam"]))

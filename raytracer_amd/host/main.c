@@ -15,7 +15,8 @@ static void usage(const char *exe) {
          "    -o PATH  output image (24-bpp BMP)\n"
          "    -G gamma   -E epsilon   -D distmod   (a .cfg file overrides them)\n"
          "    -W width -H height  override the camera resolution    -d N  GPU index\n"
-         "    -I PATH  also write primary-hit triangle ids (int32, row-major, -1 = none)\n", exe);
+         "    -I PATH  also write primary-hit triangle ids (int32, row-major, -1 = none)\n"
+         "    -B PATH  binary cache of the geometry file (written if missing or older than its source)\n", exe);
 }
 
 static char *join(const char *a, const char *b) {
@@ -26,7 +27,7 @@ static char *join(const char *a, const char *b) {
 
 int main(int argc, char **argv) {
   const char *opt[128] = {0};
-  const char *letters = "glLacCsoGEDWHdI";
+  const char *letters = "glLacCsoGEDWHdIB";
   char *g, *l, *L, *a, *c, *C;
   float gamma = 2.5f, epsilon = 0.0f, distmod = 2.0f;
   int i;
@@ -53,7 +54,7 @@ int main(int argc, char **argv) {
   if (opt['d']) rtHostSetDevice(atoi(opt['d']));
 
   errno = 0;
-  RT_Scene *scene = rtSceneLoadAll(g, l, L, a, C, gamma, epsilon, distmod);
+  RT_Scene *scene = rtSceneLoadAllCached(g, opt['B'], l, L, a, C, gamma, epsilon, distmod);  /* -B file: binary cache of the geometry */
   if (!scene) { fprintf(stderr, "unable to load scene: %s\n", rtGetErrorDesc()); return 1; }
   RT_Camera *cam = rtCameraLoad(c);
   if (!cam || errno > 0) { fprintf(stderr, "unable to load camera: %s\n", rtGetErrorDesc()); return 1; }

@@ -112,6 +112,12 @@ void rtCameraDestroy(RT_Camera **self);
 RT_Scene *rtSceneLoadAll(const char *brs, const char *lgt, const char *pnr, const char *atr, const char *cfg,
                          float gamma, float epsilon, float distmod);
 
+/* rtSceneLoad with a binary cache of the geometry file next to it (or anywhere): the cache is used when it was
+ * written for a source of the same size and modification time, and (re)written otherwise.  cache = NULL: no cache. */
+RT_Scene *rtSceneLoadCached(const char *filename, const char *cache);
+RT_Scene *rtSceneLoadAllCached(const char *brs, const char *cache, const char *lgt, const char *pnr, const char *atr, const char *cfg,
+                               float gamma, float epsilon, float distmod);
+
 /* Flattening for the GPU boundary: fills a rtgpu_scene_desc whose arrays live in `storage`
  * (malloc'd, free with rtSceneFlatFree). */
 typedef struct _RT_SceneFlat {

@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 /* Next meaningful line: skips blank lines and lines starting with "//" in column 0 (src/scene.c:16-34). */
 static char *read_line(FILE *f, char *buf, int cap) {
@@ -356,7 +357,84 @@ void rtCameraDestroy(RT_Camera **self) {
   *self = NULL;
 }
 
+/* Binary cache of a geometry file: what rtSceneLoad leaves in the triangles (nudged vertices, surface ids) and the
+ * scene's bounds, keyed by the size and modification time of the text file.  A cache that does not match its source,
+ * or cannot be read, is ignored and rewritten. */
+typedef struct { char magic[8]; int64_t src_size, src_mtime_ns; int32_t nt, pad; float dmin[3], dmax[3]; } GeomCacheHeader;
+static int source_stamp(const char *path, int64_t *size, int64_t *mtime_ns) {
+  struct stat st;
+  if (stat(path, &st)) return 0;
+  *size = (int64_t)st.st_size;
+  *mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+  return 1;
+}
+RT_Scene *rtSceneLoadCached(const char *filename, const char *cache) {
+  GeomCacheHeader h;
+  int64_t size = 0, mtime = 0;
+  RT_Scene *s = NULL;
+  FILE *f;
+  int32_t i;
+  if (!cache || !source_stamp(filename, &size, &mtime)) return rtSceneLoad(filename);
+  f = fopen(cache, "rb");
+  if (f) {
+    float *rec = NULL;
+    if (fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "RTGEOM1", 8) && h.src_size == size && h.src_mtime_ns == mtime && h.nt >= 0 &&
+        (s = calloc(1, sizeof *s)) && (s->t = calloc(h.nt > 0 ? h.nt : 1, sizeof *s->t)) && (rec = malloc(sizeof(float) * 10 * (h.nt > 0 ? h.nt : 1))) &&
+        fread(rec, sizeof(float) * 10, (size_t)h.nt, f) == (size_t)h.nt) {
+      s->nt = h.nt;
+      memcpy(s->dmin, h.dmin, 12); memcpy(s->dmax, h.dmax, 12);
+      for (i = 0; i < h.nt; i++) {
+        RT_Triangle *t = &s->t[i];
+        memcpy(t->i, rec + 10 * i, 12); memcpy(t->j, rec + 10 * i + 3, 12); memcpy(t->k, rec + 10 * i + 6, 12);
+        memcpy(&t->sid, rec + 10 * i + 9, 4);
+        t->tj[0] = 1.0f; t->tk[1] = 1.0f;
+      }
+      s->cfg.epsilon = 0.0f; s->cfg.gamma = 2.5f; s->cfg.distmod = 2.0f; s->cfg.vmode = VOX_DEFAULT;
+      free(rec); fclose(f);
+      errno = 0;
+      return s;
+    }
+    free(rec);
+    if (s) { free(s->t); free(s); s = NULL; }
+    fclose(f);
+  }
+  errno = 0;  /* (a missing cache is not an error) */
+  s = rtSceneLoad(filename);
+  {
+    const int load_errno = errno;  /* what the caller sees: whether the cache can be written does not matter */
+    if (s && load_errno == 0 && (f = fopen(cache, "wb"))) {
+      float *rec = malloc(sizeof(float) * 10 * (s->nt > 0 ? s->nt : 1));
+      int ok = rec != NULL;
+      memset(&h, 0, sizeof h);
+      memcpy(h.magic, "RTGEOM1", 8);
+      h.src_size = size; h.src_mtime_ns = mtime; h.nt = s->nt;
+      memcpy(h.dmin, s->dmin, 12); memcpy(h.dmax, s->dmax, 12);
+      for (i = 0; ok && i < s->nt; i++) {
+        const RT_Triangle *t = &s->t[i];
+        memcpy(rec + 10 * i, t->i, 12); memcpy(rec + 10 * i + 3, t->j, 12); memcpy(rec + 10 * i + 6, t->k, 12);
+        memcpy(rec + 10 * i + 9, &t->sid, 4);
+      }
+      ok = ok && fwrite(&h, sizeof h, 1, f) == 1 && fwrite(rec, sizeof(float) * 10, (size_t)s->nt, f) == (size_t)s->nt;
+      free(rec);
+      if (fclose(f) != 0) ok = 0;
+      if (!ok) remove(cache);
+    }
+    errno = load_errno;
+  }
+  return s;
+}
+
+static RT_Scene *load_all(const char *brs, const char *cache, const char *lgt, const char *pnr, const char *atr, const char *cfg,
+                          float gamma, float epsilon, float distmod);
 RT_Scene *rtSceneLoadAll(const char *brs, const char *lgt, const char *pnr, const char *atr, const char *cfg,
+                         float gamma, float epsilon, float distmod) {
+  return load_all(brs, NULL, lgt, pnr, atr, cfg, gamma, epsilon, distmod);
+}
+RT_Scene *rtSceneLoadAllCached(const char *brs, const char *cache, const char *lgt, const char *pnr, const char *atr, const char *cfg,
+                               float gamma, float epsilon, float distmod) {
+  return load_all(brs, cache, lgt, pnr, atr, cfg, gamma, epsilon, distmod);
+}
+static RT_Scene *load_all(const char *brs, const char *cache, const char *lgt, const char *pnr, const char *atr, const char *cfg,
                          float gamma, float epsilon, float distmod) {
   RT_Scene *scene;
   RT_Surface *surf;
@@ -365,7 +443,7 @@ RT_Scene *rtSceneLoadAll(const char *brs, const char *lgt, const char *pnr, cons
   if (!probe) { errno = E_IO; return NULL; } /* the reference dereferences NULL here (src/scene.c:220) */
   fclose(probe);
   errno = 0;
-  scene = rtSceneLoad(brs);
+  scene = cache ? rtSceneLoadCached(brs, cache) : rtSceneLoad(brs);
   if (!scene || errno > 0) { rtSceneDestroy(&scene); if (!errno) errno = E_IO; return NULL; }
   scene->cfg.epsilon = epsilon; scene->cfg.gamma = gamma; scene->cfg.distmod = distmod; /* src/main.c:139-141 */
   if (cfg) rtSceneConfigureRenderer(scene, cfg);

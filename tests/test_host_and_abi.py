@@ -130,3 +130,31 @@ def test_loader_float_parser_equals_strtof():
     for text in edge:
         a, na, b, nb = both(text)
         assert (a, na) == (b, nb), text
+
+
+def test_geometry_cache_gives_the_same_scene_and_notices_a_changed_source(tmp_path):
+    import shutil
+    import time
+    src = tmp_path / "scene"
+    for ext in (".brs", ".atr", ".cam", ".lgt"):
+        shutil.copy(os.path.join(ROOT, "scenes/s5/s5" + ext), str(src) + ext)
+    cache = str(tmp_path / "scene.geom")
+    plain = rt.Scene(str(src))
+    first = rt.Scene(str(src), geometry_cache=cache)      # writes the cache
+    assert os.path.getsize(cache) == 56 + 40 * plain.nt
+    t0 = time.time(); second = rt.Scene(str(src), geometry_cache=cache); cached_s = time.time() - t0  # reads it
+    for s in (first, second):
+        assert s.nt == plain.nt
+        assert np.array_equal(s.vertices().view(np.uint32), plain.vertices().view(np.uint32))
+        assert np.array_equal(s.sids(), plain.sids())
+        assert list(s.desc.dmin) == list(plain.desc.dmin) and list(s.desc.dmax) == list(plain.desc.dmax)
+    # a changed source (here: one triangle fewer is not needed; a new modification time is enough) invalidates the cache
+    lines = open(str(src) + ".brs").read().split("\n")
+    first_vertex = lines[1].split()
+    lines[1] = "%.4f %s %s" % (float(first_vertex[0]) + 1.0, first_vertex[1], first_vertex[2])
+    open(str(src) + ".brs", "w").write("\n".join(lines))
+    os.utime(str(src) + ".brs", (time.time() + 5, time.time() + 5))
+    third = rt.Scene(str(src), geometry_cache=cache)
+    fresh = rt.Scene(str(src))
+    assert np.array_equal(third.vertices().view(np.uint32), fresh.vertices().view(np.uint32))
+    assert not np.array_equal(third.vertices(), plain.vertices())
