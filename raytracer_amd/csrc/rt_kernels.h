@@ -1636,8 +1636,9 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
     }
   }
   if (valid) {
-    colors[4ll * gidx] = res.x; colors[4ll * gidx + 1] = res.y; colors[4ll * gidx + 2] = res.z;
-    if (level == 0) {
+    if (level != 0) {  // only a parent reads a node's colour, and level 0 has none
+      colors[4ll * gidx] = res.x; colors[4ll * gidx + 1] = res.y; colors[4ll * gidx + 2] = res.z;
+    } else {
       long long p = fb_base + idx;
       fb_rgb[3 * p] = res.x; fb_rgb[3 * p + 1] = res.y; fb_rgb[3 * p + 2] = res.z;
       fb_ids[p] = nd.tri >= 0 ? nd.tri : -1;
