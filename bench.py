@@ -23,7 +23,9 @@ Extra objects on the JSON line:
                 `traffic` is what the launch really moved to and from HBM (rocprofv3 counters), and
                 walk_stats says how much of the listed work was executed.
   cpu_baseline  the unmodified reference (oracle/_ref/ref_dump) or, if that binary is absent, the C
-                oracle, single-threaded on the host, on the same scene at a reduced resolution.
+                oracle, single-threaded on the host, on the same scene at a reduced resolution;
+                cpu_baseline.parallel is the C oracle on the same sample with its rows spread over the
+                host cores of this job (OpenMP).
 """
 import argparse
 import json
@@ -59,8 +61,20 @@ def cpu_baseline(prefix, over, width, height):
         t0 = time.time()
         s.render(shadow_cache=True, threads=1)
         secs, kind = time.time() - t0, "port"
-    return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": kind, "sample": sample,
-            "seconds": round(secs, 3), "rays": rays}
+    out = {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": kind, "sample": sample,
+           "seconds": round(secs, 3), "rays": rays}
+    # The same sample with the C oracle's rows spread over the host cores this job may use (the reference itself has no
+    # threads; rows in parallel need its per-light shadow cache off, so more shadow queries reach the grid walk).
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), 64))
+    if cores > 1 and scene.npl == 0:
+        s = O.OracleScene(prefix, width=width, height=height, **over)
+        t0 = time.time()
+        s.render(shadow_cache=False, threads=cores)
+        psecs = time.time() - t0
+        out["parallel"] = {"value": round(rays / psecs / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                           "sample": sample.replace("1 thread", "%d threads, rows in parallel, shadow cache off" % cores),
+                           "seconds": round(psecs, 3)}
+    return out
 
 
 def main():
