@@ -310,9 +310,10 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
   const uint32_t nb = (cnt + kBatch - 1) / kBatch;
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
     const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
-    static_assert(kHdrChunk * kHdrFloats / 4 == 96, "two 16-byte loads per lane stage a header chunk");
+    static_assert(kHdrChunk * kHdrFloats / 4 <= 192, "up to three 16-byte loads per lane stage a header chunk");
     if (lane < 3 * nh) glds16(hsrc + 3 * h0 + lane, hs);
     if (lane + 64 < 3 * nh) glds16(hsrc + 3 * h0 + lane + 64, hs + 256);
+    if (kHdrChunk > 32 && lane + 128 < 3 * nh) glds16(hsrc + 3 * h0 + lane + 128, hs + 512);
     {
       const uint32_t first = h0 * kBatch, left = cnt - first;
       const uint32_t count = left < (uint32_t)(kHdrChunk * kBatch) ? left : (uint32_t)(kHdrChunk * kBatch);
@@ -329,19 +330,19 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       maybe = box_test<true>(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle.axis,
                              bundle.m, bundle.odr, bundle.onorm, bundle.tmax, transparent_counts_anywhere, bundle.ro, bundle.rho);
     }
-    const uint32_t candidates = (uint32_t)__ballot(maybe);
-    tally(nh, nh - __popc(candidates));
+    const unsigned long long candidates = __ballot(maybe);
+    tally(nh, nh - __popcll(candidates));
     // ray by ray: which of the candidates can any ray of the wavefront meet
-    uint32_t kept = 0;
-    for (uint32_t cm = candidates; cm != 0; cm &= cm - 1) {
-      const int b = __ffs(cm) - 1;
+    unsigned long long kept = 0;
+    for (unsigned long long cm = candidates; cm != 0; cm &= cm - 1) {
+      const int b = __ffsll(cm) - 1;
       const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, radius
       const v4f hh = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);  // h, inv_cos
       const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 8);   // k1, -+k2, ga, gb
       const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w);
       tally(0, keep ? 0 : 1);
       tally(-1, 0);  // one more batch reached the ray-by-ray test
-      if (keep) kept |= 1u << b;
+      if (keep) kept |= 1ull << b;
     }
     ph.template end<3>();
     // the kept batches through two LDS buffers: the next one is on its way while this one is tested
@@ -349,18 +350,18 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     auto records_of = [&](uint32_t c0) { return (int)(beg + cnt - c0 < (uint32_t)kBatch ? beg + cnt - c0 : (uint32_t)kBatch); };
     int buf = 0;
     if (kept != 0) {
-      const uint32_t c0 = first_record(__ffs(kept) - 1);
+      const uint32_t c0 = first_record(__ffsll(kept) - 1);
       stage_batch(recs, c0, records_of(c0), rs, lane);
     }
     while (kept != 0) {
-      const int b = __ffs(kept) - 1;
+      const int b = __ffsll(kept) - 1;
       kept &= kept - 1;
       const uint32_t c0 = first_record(b);
       const int n = records_of(c0);
       const float *rb = rs + buf * (kBatch * kRecFloats);
       wait_staged();
       if (kept != 0) {
-        const uint32_t c1 = first_record(__ffs(kept) - 1);
+        const uint32_t c1 = first_record(__ffsll(kept) - 1);
         stage_batch(recs, c1, records_of(c1), rs + (buf ^ 1) * (kBatch * kRecFloats), lane);
       }
       buf ^= 1;
@@ -1674,16 +1675,16 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
 // take part.  partial: [blocks][6]; k_minmax_final folds partials into the running d_minmax.
 // End of a chunk: folds the blocks' colour ranges into the running range and, if ctl is given, the chunk's statistics
 // and queue lengths into the frame totals (k_fold_stats).
-__global__ void __launch_bounds__(256) k_minmax_final(const float *__restrict__ partial, int nblocks, float *__restrict__ minmax,
-                                                      const Ctl *__restrict__ ctl = nullptr, unsigned long long *__restrict__ totals = nullptr) {
-  __shared__ float sm[4][6];
+__global__ void __launch_bounds__(1024) k_minmax_final(const float *__restrict__ partial, int nblocks, float *__restrict__ minmax,
+                                                       const Ctl *__restrict__ ctl = nullptr, unsigned long long *__restrict__ totals = nullptr) {
+  __shared__ float sm[16][6];
   if (ctl != nullptr) {
     const int t = threadIdx.x;
     if (t < kStatCount) totals[t] += ctl->stat[t];
     else if (t < kStatCount + kMaxLevels) totals[t] += (unsigned long long)ctl->count[t - kStatCount];
   }
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
-  for (int b = threadIdx.x; b < nblocks; b += 256) mm_fold(mn, mx, partial + 6 * b, partial + 6 * b + 3);
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) mm_fold(mn, mx, partial + 6 * b, partial + 6 * b + 3);
   for (int off = 32; off > 0; off >>= 1) {
     float omn[3], omx[3];
 #pragma unroll
@@ -1695,7 +1696,7 @@ __global__ void __launch_bounds__(256) k_minmax_final(const float *__restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     float fmn[3] = {minmax[0], minmax[1], minmax[2]}, fmx[3] = {minmax[3], minmax[4], minmax[5]};  // the running range of earlier chunks
-    for (int wv = 0; wv < 4; wv++) mm_fold(fmn, fmx, sm[wv], sm[wv] + 3);
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) mm_fold(fmn, fmx, sm[wv], sm[wv] + 3);
     for (int k = 0; k < 3; k++) { minmax[k] = fmn[k]; minmax[3 + k] = fmx[k]; }
   }
 }
@@ -1721,16 +1722,32 @@ __global__ void k_fold_stats(const Ctl *__restrict__ ctl, unsigned long long *__
 // ------------------------------------------------------------------------------------------------
 // Tone map (raytrace.c:433-466): v = pow((c - min) * delta, gamma) * 255 in double, rounded to float,
 // truncated to an integer, low byte kept; packed R<<24 | G<<16 | B<<8 (bitmap.h:70).
+// When 2 gamma is a small integer (the default gamma is 2.5) the power is a few products and a square root, within
+// 1e-15 of the true value: if every value within 1e-12 of it gives the same byte, so does any correctly working
+// pow, and the call is skipped; the few values next to a rounding boundary take the pow path like all others.
 __global__ void __launch_bounds__(256) k_tonemap(const float *__restrict__ rgb, long long n, const float *__restrict__ minmax,
                                                  float gamma, uint32_t *__restrict__ rgba) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
+  const float twice = gamma + gamma;
+  const int halves = (twice >= 1.0f && twice <= 8.0f && twice == (float)(int)twice) ? (int)twice : 0;  // gamma = halves / 2
   uint32_t ch[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     float delta = 1.0f / (minmax[3 + k] - minmax[k]);
-    float acc = (float)(pow((double)((rgb[3 * p + k] - minmax[k]) * delta), (double)gamma) * 255.0);
-    ch[k] = f2u_x86(acc / 1.0f) & 0xffu;
+    const float x = (rgb[3 * p + k] - minmax[k]) * delta;
+    bool done = false;
+    if (halves != 0 && x >= 0.0f && x <= 4.0f) {
+      const double xd = (double)x;
+      double pw = (halves & 1) ? sqrt(xd) : 1.0;
+      for (int q = 0; q < (halves >> 1); q++) pw *= xd;
+      const uint32_t lo = f2u_x86((float)(pw * (1.0 - 1e-12) * 255.0) / 1.0f), hi = f2u_x86((float)(pw * (1.0 + 1e-12) * 255.0) / 1.0f);
+      if (lo == hi) { ch[k] = lo & 0xffu; done = true; }
+    }
+    if (!done) {
+      float acc = (float)(pow((double)x, (double)gamma) * 255.0);
+      ch[k] = f2u_x86(acc / 1.0f) & 0xffu;
+    }
   }
   rgba[p] = (ch[0] << 24) | (ch[1] << 16) | (ch[2] << 8);
 }

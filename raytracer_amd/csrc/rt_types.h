@@ -35,7 +35,11 @@ constexpr int kRecFloats = 20;
 #endif
 constexpr int kBatch = RT_BATCH; // records per batch of a cell's list: the unit of culling and of LDS staging
 static_assert(kBatch == 8 || kBatch == 16 || kBatch == 32 || kBatch == 64, "a wavefront builds the bounds of 64 / kBatch batches at a time");
-constexpr int kHdrChunk = 32;    // batch headers staged in LDS at a time
+#ifndef RT_HDR_CHUNK
+#define RT_HDR_CHUNK 32
+#endif
+constexpr int kHdrChunk = RT_HDR_CHUNK;  // batch headers staged in LDS at a time (one lane per header in the bundle test)
+static_assert(kHdrChunk == 32 || kHdrChunk == 64, "the masks of a header chunk are 64 bits wide");
 constexpr int kHdrFloats = 12;
 
 // Header of one batch (positions kBatch*b .. kBatch*b + kBatch-1 of a cell's list): the axis-aligned box

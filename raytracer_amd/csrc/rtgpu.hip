@@ -648,7 +648,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   }
   {
     Span sp(c, W_MINMAX);
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, c->stream, c->d_partial, (n0 + 255) / 256, d_minmax,
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(1024), 0, c->stream, c->d_partial, (n0 + 255) / 256, d_minmax,
                        (const Ctl *)c->d_ctl, c->d_totals);  // also the chunk's statistics into the frame totals
   }
   return RTGPU_OK;
