@@ -184,33 +184,49 @@ RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t coun
 // delta = 1e-5 (2 |o| + tv) >= 1e-5 (|o| + |c|), far above the rounding of (c - o) x r and tc, is added to W and to
 // every comparison (the separating direction vanishes for an axis-parallel ray: 0 <= 0 must not be decided by
 // rounding).  A NaN compares false: not culled.
-// BUNDLE: the ray is a bundle's leader and the answer is for every ray of the bundle at once (onorm, tmax: the
-// bundle's maxima).  A point of such a ray at parameter t is within ro + |t| rho of the leader's point at t, and
-// |t| <= tv + |h| + 2 W where the ray meets the widened box, so the extents grow by that much more; tv by ro.
-template <bool BUNDLE>
-RT_D bool box_test(f3 c, float radius, f3 h, bool transparent, float inv_cos, float ga, float gb, float slack, f3 r, f3 m,
-                   float odr, float onorm, float tmax_opaque, bool transparent_counts_anywhere, float ro = 0.0f, float rho = 0.0f) {
-  const float ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
-  const float ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
-  const float ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
-  const float d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
-  const float tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
-  const float on5 = 0.00001f * onorm;
-  float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(tc, tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
-  if (BUNDLE) tv = __builtin_fmaf(ro, 1.001f, tv);
-  const float delta = __builtin_fmaf(0.00001f, tv, on5 + on5);
-  float W = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, delta) + slack;
-  if (BUNDLE) W += __builtin_fmaf(rho, tv + (h.x + h.y + h.z) + (W + W), ro) * 1.001f;
-  const float hx = h.x + W, hy = h.y + W, hz = h.z + W;
+// Two levels.  box_test_bundle: the ray is a bundle's leader and the answer is for every ray of the bundle at once
+// (onorm, tmax: the bundle's maxima).  A point of such a ray at parameter t is within ro + |t| rho of the leader's
+// point at t, and |t| <= tv + |h| + 2 W where the ray meets the widened box, so the extents grow by that much more;
+// tv by ro.  It hands back W before that growth and delta: tv and onorm there are upper bounds of every ray's own,
+// so these two serve any single ray of the bundle.  box_test_ray: one ray against the box widened by them (the
+// walk kernels keep c, -+delta, h + W, W in their LDS copy of the header; delta's sign bit marks a batch with a
+// transparent triangle).
+struct BoxRay { float ex, ey, ez, tc; };
+RT_D BoxRay box_ray(f3 c, f3 r, f3 m, float odr) {
+  BoxRay b;
+  b.ex = __builtin_fmaf(-c.z, r.y, __builtin_fmaf(c.y, r.z, -m.x));
+  b.ey = __builtin_fmaf(-c.x, r.z, __builtin_fmaf(c.z, r.x, -m.y));
+  b.ez = __builtin_fmaf(-c.y, r.x, __builtin_fmaf(c.x, r.y, -m.z));
+  b.tc = __builtin_fmaf(c.x, r.x, __builtin_fmaf(c.y, r.y, __builtin_fmaf(c.z, r.z, -odr)));
+  return b;
+}
+// hw = h + W.  true = separated: no point of the ray with a parameter in [0, tmax] lies in the widened box
+RT_D bool box_separated(const BoxRay &b, f3 r, f3 hw, float W, float delta, float tmax) {
   const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
-  const float sx = __builtin_fmaf(hy, az, __builtin_fmaf(hz, ay, delta));
-  const float sy = __builtin_fmaf(hx, az, __builtin_fmaf(hz, ax, delta));
-  const float sz = __builtin_fmaf(hx, ay, __builtin_fmaf(hy, ax, delta));
-  const float hr = __builtin_fmaf(hx, ax, __builtin_fmaf(hy, ay, __builtin_fmaf(hz, az, W)));
-  // shadow walk: a transparent triangle attenuates wherever it is hit (d >= 0); an opaque one matters only before tmax_opaque
+  const float sx = __builtin_fmaf(hw.y, az, __builtin_fmaf(hw.z, ay, delta));
+  const float sy = __builtin_fmaf(hw.x, az, __builtin_fmaf(hw.z, ax, delta));
+  const float sz = __builtin_fmaf(hw.x, ay, __builtin_fmaf(hw.y, ax, delta));
+  const float hr = __builtin_fmaf(hw.x, ax, __builtin_fmaf(hw.y, ay, __builtin_fmaf(hw.z, az, W)));
+  return (__builtin_fabsf(b.ex) > sx) | (__builtin_fabsf(b.ey) > sy) | (__builtin_fabsf(b.ez) > sz) | (b.tc + hr < 0.0f) | (b.tc - hr > tmax);
+}
+RT_D bool box_test_bundle(f3 c, float radius, f3 h, bool transparent, float inv_cos, float ga, float gb, float slack, const Bundle &bu,
+                          bool transparent_counts_anywhere, float &w_ray, float &delta) {
+  const BoxRay b = box_ray(c, bu.axis, bu.m, bu.odr);
+  const float d2 = __builtin_fmaf(b.ex, b.ex, __builtin_fmaf(b.ey, b.ey, b.ez * b.ez));
+  const float on5 = 0.00001f * bu.onorm;
+  float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(b.tc, b.tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
+  tv = __builtin_fmaf(bu.ro, 1.001f, tv);
+  delta = __builtin_fmaf(0.00001f, tv, on5 + on5);
+  w_ray = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, delta) + slack;
+  const float W = w_ray + __builtin_fmaf(bu.rho, tv + (h.x + h.y + h.z) + (w_ray + w_ray), bu.ro) * 1.001f;
+  // shadow walk: a transparent triangle attenuates wherever it is hit (d >= 0); an opaque one matters only before tmax
+  const float tmax = (transparent_counts_anywhere & transparent) ? INFINITY : bu.tmax;
+  return !box_separated(b, bu.axis, mk3(h.x + W, h.y + W, h.z + W), W, delta, tmax);
+}
+RT_D bool box_test_ray(f3 c, float delta_and_flag, f3 hw, float W, f3 r, f3 m, float odr, float tmax_opaque, bool transparent_counts_anywhere) {
+  const bool transparent = __float_as_int(delta_and_flag) < 0;
   const float tmax = (transparent_counts_anywhere & transparent) ? INFINITY : tmax_opaque;
-  const bool out = (__builtin_fabsf(ex) > sx) | (__builtin_fabsf(ey) > sy) | (__builtin_fabsf(ez) > sz) | (tc + hr < 0.0f) | (tc - hr > tmax);
-  return !out;
+  return !box_separated(box_ray(c, r, m, odr), r, hw, W, __builtin_fabsf(delta_and_flag), tmax);
 }
 
 // Where a walk kernel's wavefronts spend their time: a diagnostic that exists only in builds with -DRT_PHASES
@@ -322,24 +338,30 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       batch_cos(g.cell_nrm, beg + first, count, hs, lane, bundle, f0);
     }
     ph.template end<2>();
-    // one lane per batch: can any ray of the bundle meet the batch's box at all?
+    // one lane per batch: can any ray of the bundle meet the batch's box at all?  If so the lane rewrites its header
+    // for the ray-by-ray test: c, -+delta, h + W, W (box_test_ray)
     bool maybe = false;
     if (lane < nh) {
-      const float *H = hs + lane * kHdrFloats;
+      float *H = hs + lane * kHdrFloats;
       const v4f hc = *reinterpret_cast<const v4f *>(H), hh = *reinterpret_cast<const v4f *>(H + 4), k = *reinterpret_cast<const v4f *>(H + 8);
-      maybe = box_test<true>(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle.axis,
-                             bundle.m, bundle.odr, bundle.onorm, bundle.tmax, transparent_counts_anywhere, bundle.ro, bundle.rho);
+      float w_ray, delta;
+      maybe = box_test_bundle(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle,
+                              transparent_counts_anywhere, w_ray, delta);
+      if (maybe) {
+        H[3] = k.y < 0.0f ? -delta : delta;
+        *reinterpret_cast<v4f *>(H + 4) = v4f{hh.x + w_ray, hh.y + w_ray, hh.z + w_ray, w_ray};
+      }
     }
+    __builtin_amdgcn_wave_barrier();
     const unsigned long long candidates = __ballot(maybe);
     tally(nh, nh - __popcll(candidates));
     // ray by ray: which of the candidates can any ray of the wavefront meet
     unsigned long long kept = 0;
     for (unsigned long long cm = candidates; cm != 0; cm &= cm - 1) {
       const int b = __ffsll(cm) - 1;
-      const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, radius
-      const v4f hh = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);  // h, inv_cos
-      const v4f k = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 8);   // k1, -+k2, ga, gb
-      const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w);
+      const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, -+delta
+      const v4f hw = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);  // h + W, W
+      const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hw.x, hw.y, hw.z), hw.w);
       tally(0, keep ? 0 : 1);
       tally(-1, 0);  // one more batch reached the ray-by-ray test
       if (keep) kept |= 1ull << b;
@@ -859,7 +881,7 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, const uint32_t *__
     if (valid) {
       const TriRec &R = g.cell_tris[p];
       k1 = R.k1; k2 = R.k2; transparent = R.kt > 0.0f ? 1.0f : 0.0f;
-      // gb = 32 eps L^2 / |n|, ga = 0.9 gb L  (see box_test); L from k1 = 144 eps L
+      // gb = 32 eps L^2 / |n|, ga = 0.9 gb L  (see box_test_bundle); L from k1 = 144 eps L
       const float L = R.k1 * (1.0f / (144.0f * 5.9604644775390625e-8f));
       gb = (32.0f * 5.9604644775390625e-8f) * L * L / sqrtf(R.n[0] * R.n[0] + R.n[1] * R.n[1] + R.n[2] * R.n[2]) * 1.0001f;
       ga = 0.9f * gb * L * 1.0001f;
@@ -1080,8 +1102,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_nearest(GridP g, const Ray *_
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
         stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, ph,
-                    [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
-                      return wave_any(proc & box_test<false>(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, best, false));
+                    [&](f3 c, float delta, f3 hw, float W) {
+                      return wave_any(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
                     [&](int n, int culled) {
                       if (n >= 0) { if (COUNT) { nBatch += n; nCull += culled; } }
@@ -1459,9 +1481,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
           stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, ph,
-                      [&](f3 c, float radius, f3 hx, bool transparent, float inv_cos, float ga, float gb) {
-                        return wave_any(in_group & (result >= 0.0f) &
-                                        box_test<false>(c, radius, hx, transparent, inv_cos, ga, gb, g.slack, r, pm, odr, onorm, dmax, true));
+                      [&](f3 c, float delta, f3 hw, float W) {
+                        return wave_any(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },
                       [&](int n, int culled) {
                         if (n >= 0) { if (COUNT) { nBatch += n; nCull += culled; } }

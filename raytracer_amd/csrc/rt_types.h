@@ -46,8 +46,9 @@ constexpr int kHdrFloats = 12;
 // (centre c, half extents h) and the sphere (c, radius) that contain every triangle of the batch, both already
 // inflated for rounding; the maxima of the records' k1, k2, with k2 negated if any triangle of the batch is
 // transparent (kt > 0); and the batch's constants ga, gb of the bound of what rounding can add to the box
-// (box_test in rt_kernels.h).  inv_cos is scratch: the walk kernels keep the visit's bound of
-// 1 / |cos(ray, normal)| for the batch there, in their LDS copy.
+// (box_test_bundle in rt_kernels.h).  inv_cos is scratch: the walk kernels keep the visit's bound of
+// 1 / |cos(ray, normal)| for the batch there, in their LDS copy, and for a batch the bundle test lets through they
+// overwrite radius, h and inv_cos of that copy with -+delta, h + W and W for the ray-by-ray test.
 struct __attribute__((aligned(16))) BatchHdr {
   float c[3];
   float radius;

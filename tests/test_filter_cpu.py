@@ -136,32 +136,57 @@ def batch_cos(H, axis, rho):
         return np.where(cosb > least, (F(1.0) / cosb).astype(F) * F(1.01), F(np.inf)).astype(F)
 
 
-def box_may_hit(H, inv_cos, r, m, odr, onorm, tmax, ro=None, rho=None):
-    """box_test of rt_kernels.h, operation by operation in float32 (ro, rho given: the bundle variant)."""
+def _box_ray(c, r, m, odr):
+    ex = fma(-c[:, 2], r[:, 1], fma(c[:, 1], r[:, 2], -m[:, 0]))
+    ey = fma(-c[:, 0], r[:, 2], fma(c[:, 2], r[:, 0], -m[:, 1]))
+    ez = fma(-c[:, 1], r[:, 0], fma(c[:, 0], r[:, 1], -m[:, 2]))
+    tc = fma(c[:, 0], r[:, 0], fma(c[:, 1], r[:, 1], fma(c[:, 2], r[:, 2], -odr)))
+    return ex, ey, ez, tc
+
+
+def _box_separated(e, r, hw, W, delta, tmax):
+    ex, ey, ez, tc = e
+    hx, hy, hz = hw
+    ax, ay, az = np.abs(r[:, 0]), np.abs(r[:, 1]), np.abs(r[:, 2])
+    sx = fma(hy, az, fma(hz, ay, delta))
+    sy = fma(hx, az, fma(hz, ax, delta))
+    sz = fma(hx, ay, fma(hy, ax, delta))
+    hr = fma(hx, ax, fma(hy, ay, fma(hz, az, W)))
+    return (np.abs(ex) > sx) | (np.abs(ey) > sy) | (np.abs(ez) > sz) | (tc + hr < 0) | (tc - hr > tmax)
+
+
+def bundle_box_may_hit(H, inv_cos, axis, ml, odl, onorm, tmax, ro, rho):
+    """box_test_bundle of rt_kernels.h, operation by operation in float32: the leader's ray (axis, ml, odl) for every
+    ray within ro, rho of it.  Returns (may hit, W for a single ray of the bundle, delta)."""
     c, h = H["c"], H["h"]
     k = lambda x: np.full_like(onorm, F(x))
     with np.errstate(all="ignore"):
-        ex = fma(-c[:, 2], r[:, 1], fma(c[:, 1], r[:, 2], -m[:, 0]))
-        ey = fma(-c[:, 0], r[:, 2], fma(c[:, 2], r[:, 0], -m[:, 1]))
-        ez = fma(-c[:, 1], r[:, 0], fma(c[:, 0], r[:, 1], -m[:, 2]))
+        e = _box_ray(c, axis, ml, odl)
+        ex, ey, ez, tc = e
         d2 = fma(ex, ex, fma(ey, ey, ez * ez))
-        tc = fma(c[:, 0], r[:, 0], fma(c[:, 1], r[:, 1], fma(c[:, 2], r[:, 2], -odr)))
         on5 = F(0.00001) * onorm
         tv = fma(np.sqrt(fma(tc, tc, d2)), k(1.001), on5 + H["radius"])
-        if ro is not None:
-            tv = fma(ro, k(1.001), tv)
+        tv = fma(ro, k(1.001), tv)
         delta = fma(k(0.00001), tv, on5 + on5)
-        W = fma(fma(H["gb"], tv, H["ga"]), inv_cos, delta)
-        if ro is not None:
-            W = W + fma(rho, tv + (h[:, 0] + h[:, 1] + h[:, 2]) + (W + W), ro) * F(1.001)
-        hx, hy, hz = h[:, 0] + W, h[:, 1] + W, h[:, 2] + W
-        ax, ay, az = np.abs(r[:, 0]), np.abs(r[:, 1]), np.abs(r[:, 2])
-        sx = fma(hy, az, fma(hz, ay, delta))
-        sy = fma(hx, az, fma(hz, ax, delta))
-        sz = fma(hx, ay, fma(hy, ax, delta))
-        hr = fma(hx, ax, fma(hy, ay, fma(hz, az, W)))
-        out = (np.abs(ex) > sx) | (np.abs(ey) > sy) | (np.abs(ez) > sz) | (tc + hr < 0) | (tc - hr > tmax)
+        w_ray = fma(fma(H["gb"], tv, H["ga"]), inv_cos, delta)
+        W = w_ray + fma(rho, tv + (h[:, 0] + h[:, 1] + h[:, 2]) + (w_ray + w_ray), ro) * F(1.001)
+        out = _box_separated(e, axis, (h[:, 0] + W, h[:, 1] + W, h[:, 2] + W), W, delta, tmax)
+    return ~out, w_ray, delta
+
+
+def ray_box_may_hit(H, w_ray, delta, r, m, odr, tmax):
+    """box_test_ray of rt_kernels.h: one ray of a bundle against the box widened by the bundle's W and delta."""
+    c, h = H["c"], H["h"]
+    with np.errstate(all="ignore"):
+        out = _box_separated(_box_ray(c, r, m, odr), r, (h[:, 0] + w_ray, h[:, 1] + w_ray, h[:, 2] + w_ray), w_ray, delta, tmax)
     return ~out
+
+
+def box_may_hit(H, inv_cos, r, m, odr, onorm, tmax):
+    """Both levels for a bundle of this one ray (ro = 0, rho = 1e-7, as make_bundle gives)."""
+    zero, tiny = np.zeros_like(onorm), np.full_like(onorm, F(1e-7))
+    b, w_ray, delta = bundle_box_may_hit(H, inv_cos, r, m, odr, onorm, tmax, zero, tiny)
+    return b & ray_box_may_hit(H, w_ray, delta, r, m, odr, tmax)
 
 
 def make_cases(rng, n, scale, offset, aim):
@@ -265,9 +290,13 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
         dorg = o - ol
         ro = (np.sqrt(dot32(dorg, dorg)) * F(1.001)).astype(F)
         onb = np.maximum(onorm, onl)
-        assert box_may_hit(H, inv_cos, axis, ml, odl, onb, np.full(n, np.inf, F), ro, rho)[acc].all(), "bundle test culled an accepted hit"
-        assert box_may_hit(H, inv_cos, axis, ml, odl, onb, best, ro, rho)[acc & (d < best)].all(), "bundle test culled a nearer hit"
-        assert box_may_hit(H, inv_cos, axis, ml, odl, onb, dmax, ro, rho)[blocker].all(), "bundle test culled a blocker"
+        for bound, which, what in ((np.full(n, np.inf, F), acc, "an accepted hit"), (best, acc & (d < best), "a nearer hit"),
+                                   (dmax, blocker, "a blocker")):
+            tb = np.maximum(bound, bound[::-1])  # the bundle's bound is the largest of its rays'
+            may, w_ray, delta = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, tb, ro, rho)
+            assert may[which].all(), "bundle test culled " + what
+            # ... and with the bundle's W and delta this ray's own test must not cull it either
+            assert ray_box_may_hit(H, w_ray, delta, r, m, odr, bound)[which].all(), "ray test with the bundle's margins culled " + what
     fuzz = batch_cos(H, r, np.full(n, F(1e-7), F))
     # the filter is not vacuous: it rejects most misses and proves most clear hits
     if aim is aim_anywhere:
