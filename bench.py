@@ -86,8 +86,8 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-width", type=int, default=640)
-    ap.add_argument("--cpu-height", type=int, default=360)
+    ap.add_argument("--cpu-width", type=int, default=960)
+    ap.add_argument("--cpu-height", type=int, default=540)
     args = ap.parse_args()
 
     # Libraries below write banners to the C-level stdout (RCCL prints its version when a communicator is made); the
