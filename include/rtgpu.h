@@ -134,7 +134,7 @@ int rtgpu_set_stream(rtgpu_ctx *ctx, void *hip_stream);
 int rtgpu_set_null_stream(rtgpu_ctx *ctx);
 
 /* Options: "count" (0/1) S/T counters, "timing" (0/1) per-kernel events, "chunk_bytes" (device
- * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default, 24), "pipeline" (default 1: rtgpu_frame_begin builds on its
+ * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default: what each walk kernel is compiled for, 20 and 24), "pipeline" (default 1: rtgpu_frame_begin builds on its
  * own stream into the buffers the previous frame does not use, overlapping that frame's kernels; 0: on the context's stream),
  * "filter" (default 1; 0 switches off the conservative triangle filter and the batch culling of the
  * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */

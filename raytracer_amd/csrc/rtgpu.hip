@@ -33,7 +33,7 @@ struct rtgpu_ctx {
   // options
   bool opt_count = false, opt_timing = false;
   int64_t chunk_bytes = 8ll << 30;
-  int waves_per_cu = 4 * RT_WAVES;  // what the walk kernels are compiled for (their register budget)
+  int waves_per_cu = 0;  // wavefronts per CU of the persistent walk kernels; 0 = what each is compiled for (its register budget)
   bool opt_pipeline = true;  // frame set-up on its own stream, into the set of buffers the previous frame does not use
   bool filter = true;        // staged triangle filter + batch culling (off: every listed triangle gets the exact test)
   // scene, host side
@@ -344,7 +344,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
-  else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = value == 0 ? 4 * RT_WAVES : (int)value; }
+  else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
   return RTGPU_OK;
 }
@@ -568,7 +568,7 @@ namespace {
 // (raytrace.c:170-204); with planar lights also the number of shaded hits in every node's subtree.
 int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   const int n0 = nt_chunk * kTilePixels;
-  const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
+  const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * RT_WAVES_NEAREST) + 3) / 4);
   const int64_t tx = tiles_x_of(c);
   {
     Span sp(c, W_PRIMARY);  // (k_primary also resets the control block)
@@ -628,7 +628,7 @@ int chunk_ranks(rtgpu_ctx *c, int n0, const int32_t *sizes, int64_t per_rank, in
 // Second half: shadow walks, colours deepest level first, colour range, statistics.
 int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d_ids, float *d_minmax) {
   const int n0 = nt_chunk * kTilePixels;
-  const int pgrid = c->num_cu * ((c->waves_per_cu + 3) / 4);
+  const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * RT_WAVES) + 3) / 4);
   if (c->shade.nslots > 0) {
     for (int L = 0; L < c->levels; L++) {
       Span sp(c, W_SHADOW);
