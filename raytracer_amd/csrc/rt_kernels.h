@@ -247,6 +247,14 @@ __device__ uint32_t g_ticket_log[2][kTicketLog][kTicketWords];
 struct TicketLog {
   unsigned long long t0; uint32_t visits, batches, tests;
   RT_D void begin() { t0 = __builtin_amdgcn_s_memtime(); visits = batches = tests = 0; }
+  // a wavefront's life: g_phase[which * 8 + 0..2] += clocks inside tickets, clocks from entry to exit, 1; [3] = the longest life
+  static RT_D void life(int which, int lane, unsigned long long busy, unsigned long long born) {
+    const unsigned long long all = __builtin_amdgcn_s_memtime() - born;
+    if (lane == 0) {
+      atomicAdd(&g_phase[which * 8], busy); atomicAdd(&g_phase[which * 8 + 1], all); atomicAdd(&g_phase[which * 8 + 2], 1ull);
+      atomicMax(&g_phase[which * 8 + 3], all);
+    }
+  }
   template <typename PH>
   RT_D void end(int which, uint32_t base, int lane, PH &ph) {
     const unsigned long long t = __builtin_amdgcn_s_memtime() - t0;
@@ -1026,6 +1034,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
   Phases ph;
   ph.begin();
+  RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
   Tickets tickets((unsigned long long)nrays);
   for (;;) {
     uint32_t base;
@@ -1175,9 +1184,10 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
       ph.end<6>();
     }
     if (idx < nrays) hits[idx] = h;
-    RT_TICKET(ph.end<0>(); if (level == 0) tl.end(0, base, lane, ph);)
+    RT_TICKET(ph.end<0>(); if (level == 0) tl.end(0, base, lane, ph); busy += __builtin_amdgcn_s_memtime() - tl.t0;)
     nHits += __popcll(__ballot(h.tri >= 0));
   }
+  RT_TICKET(if (level == 0) TicketLog::life(0, lane, busy, born);)
   ph.end<0>();
   ph.flush(0, lane);
   if (lane == 0) {
@@ -1380,6 +1390,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
   Phases ph;
   ph.begin();
+  RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
   Tickets tickets((unsigned long long)total);
   for (;;) {
     uint32_t base;
@@ -1560,8 +1571,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       ph.end<6>();
     }
     if (have_result) ts_out[(long long)(node_base + nidx) * sp.nslots + slot] = result < 0.0f ? -1.0f : ts;
-    RT_TICKET(ph.end<0>(); if (level == 0) tl.end(1, base, lane, ph);)
+    RT_TICKET(ph.end<0>(); if (level == 0) tl.end(1, base, lane, ph); busy += __builtin_amdgcn_s_memtime() - tl.t0;)
   }
+  RT_TICKET(if (level == 0) TicketLog::life(1, lane, busy, born);)
   ph.end<0>();
   ph.flush(8, lane);
   if (COUNT) {

@@ -40,6 +40,15 @@ def main():
         r.render(rgb, ids, mm, 0, world)
     t = r.timings().asdict()
     L = rt.gpu_lib()
+    # how much of their life the wavefronts spend inside tickets, and how much longer the last one lives than the average
+    L.rtgpu_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+    life = (C.c_int64 * 16)()
+    L.rtgpu_phase_cycles(r._h, life, 1)  # (sums over the frames rendered above: the ratios stay what they are)
+    for which, kind in enumerate(("nearest", "shadow")):
+        busy, alive, waves, longest = life[8 * which:8 * which + 4]
+        if waves:
+            print("%s walk: wavefronts spend %.1f %% of their life inside tickets; mean life %.0f clocks, longest %d"
+                  % (kind, 100.0 * busy / alive, alive / waves, longest))
     L.rtgpu_ticket_log.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     tiles_x = (w + 7) // 8
     for which, kind in enumerate(("nearest", "shadow")):
