@@ -171,11 +171,13 @@ def main():
         per_launch = args.steps / launches  # frames per launch of this family (1 when the frame is one chunk)
         alg_bytes = (64.0 * q + 8.0 * S + 40.0 * T) * per_launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        traffic, l2_hit = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and world == 1:  # (the counters were collected on whole-frame launches)
             try:
-                traffic = json.load(open(tfile)).get("k_" + fam, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile)).get("k_" + fam, {})
+                traffic = tj.get("hbm_bytes_per_launch")
+                l2_hit = tj.get("l2_hit_rate")
             except Exception:
                 traffic = None
         # what really bounds the kernel: instruction issue.  Wave-instructions and cycles of one launch from the SQ
@@ -189,7 +191,12 @@ def main():
                 cycles = pm.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
                 if insts > 0 and cycles > 0:
                     cpi = cycles * 1024.0 / insts  # 256 CUs x 4 SIMDs
+                    waves = pm.get("SQ_WAVES", 0.0)
                     issue = {"wave_instructions_per_launch": int(insts), "cycles_per_launch": int(cycles),
+                             "valu_share_of_instructions": round(pm.get("SQ_INSTS_VALU", 0.0) / insts, 3),
+                             # a wave64 VALU instruction occupies the 32-lane SIMD for two cycles
+                             "valu_busy_frac": round(2.0 * pm.get("SQ_INSTS_VALU", 0.0) / (cycles * 1024.0), 3),
+                             "resident_waves_per_simd": round(waves / 1024.0, 2) if waves else None,
                              "cycles_per_instruction_per_simd": round(cpi, 3), "machine_cycles_per_instruction": 2.1,
                              "frac": round(2.1 / cpi, 3), "source": "profiles/pmc.json (rocprofv3 --pmc of an earlier run of this workload)"}
             except Exception:
@@ -209,6 +216,8 @@ def main():
                               "stream, where the set-up of frame k+1 overlaps the walk kernels of frame k (alone it takes 0.27 ms)",
             "roofline": {"bound": "hbm", "kernel": "k_" + fam, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "hbm_gbs_measured": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+                         "l2_hit_rate": round(l2_hit, 4) if l2_hit is not None else None,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                          "listed_tests_per_launch": int(T * per_launch),
                          "executed_tests_frac": round(cnt[fam + "_lane_slots"] / T, 4) if T else None,
