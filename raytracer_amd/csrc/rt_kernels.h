@@ -1,7 +1,7 @@
 // HIP kernels of the trace path (gfx950, wave64).  Included once by rtgpu.hip.
 //
 // Frame set-up          k_preprocess, k_tri_boxes, k_grid_offsets, k_grid_fill
-// Pixel loop (a chunk)  k_primary -> [k_nearest -> k_hit] per recursion level -> k_shadow per level
+// Pixel loop (a chunk)  k_chunk_init -> [k_nearest -> k_hit] per recursion level -> k_shadow per level
 //                       -> k_accumulate per level, deepest first (level 0 folds the colour range of its blocks) -> k_minmax_final
 // After the exchange    k_tonemap, k_untile
 #pragma once
@@ -975,37 +975,46 @@ RT_D bool walk_to_occupied(const GridP &g, const uint32_t *occ_s, bool in_lds, f
 // ------------------------------------------------------------------------------------------------
 // Primary rays of a chunk of tiles (vectormath.h:108-118, voxelize.c:417-471).  Ray index = local
 // tile * 64 + (y&7)*8 + (x&7), so one wavefront of the nearest-hit kernel is one 8x8 pixel tile.
-__global__ void __launch_bounds__(256) k_primary(CameraD cam, GridP g, int tile0, int ntiles, int rank, int world,
-                                                 int tiles_x, Ray *__restrict__ rays, Ctl *__restrict__ ctl) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0) {  // also resets the chunk's control block: queue lengths, tickets, statistics
-    static_assert(sizeof(Ctl) % 4 == 0 && sizeof(Ctl) / 4 <= 256, "one thread per word of the control block");
-    if (threadIdx.x < sizeof(Ctl) / 4) reinterpret_cast<uint32_t *>(ctl)[threadIdx.x] = 0u;
-    __syncthreads();
-    if (threadIdx.x == 0) ctl->count[0] = ntiles * kTilePixels;
-  }
-  if (idx >= ntiles * kTilePixels) return;
-  int lt = tile0 + (idx >> 6), slot = idx & 63;
-  long long gt = (long long)lt * world + rank;
-  int x = (int)(gt % tiles_x) * kTile + (slot & 7), y = (int)(gt / tiles_x) * kTile + (slot >> 3);
+// primary_dir: the pixel's ray direction, false = index past the chunk or pixel outside the image.
+RT_D bool primary_dir(const PrimaryP &pp, int idx, f3 &dir) {
+  dir = mk3(0.0f, 0.0f, 0.0f);
+  if (idx >= pp.ntiles * kTilePixels) return false;
+  const CameraD &cam = pp.cam;
+  const int lt = pp.tile0 + (idx >> 6), slot = idx & 63;
+  const long long gt = (long long)lt * pp.world + pp.rank;
+  const int x = (int)(gt % pp.tiles_x) * kTile + (slot & 7), y = (int)(gt / pp.tiles_x) * kTile + (slot >> 3);
+  if (!(x < cam.sw && y < cam.sh)) return false;
+  float w_inv = 1.0f / cam.sw, h_inv = 1.0f / cam.sh;
+  float xc = x * w_inv, yc = y * h_inv;
+  f3 ul = ld3(cam.ul), ur = ld3(cam.ur), bl = ld3(cam.bl), ob = ld3(cam.ob);
+  dir = mk3(xc * (ur.x - ul.x) + yc * (bl.x - ul.x) + ul.x - ob.x,
+            xc * (ur.y - ul.y) + yc * (bl.y - ul.y) + ul.y - ob.y,
+            xc * (ur.z - ul.z) + yc * (bl.z - ul.z) + ul.z - ob.z);
+  dir = normalize3(dir);
+  return true;
+}
+// The ray as the walk wants it: with its start voxel (i = -1: it never enters the grid, -2: no pixel).
+RT_D Ray primary_ray(const PrimaryP &pp, const GridP &g, int idx, bool with_voxel) {
   Ray ry;
-  ry.o[0] = cam.ob[0]; ry.o[1] = cam.ob[1]; ry.o[2] = cam.ob[2];
+  ry.o[0] = pp.cam.ob[0]; ry.o[1] = pp.cam.ob[1]; ry.o[2] = pp.cam.ob[2];
   ry.current = -1; ry.pad[0] = ry.pad[1] = 0;
-  ry.r[0] = ry.r[1] = ry.r[2] = 0.0f;
   ry.i = -2; ry.j = ry.k = 0;
-  if (x < cam.sw && y < cam.sh) {
-    float w_inv = 1.0f / cam.sw, h_inv = 1.0f / cam.sh;
-    float xc = x * w_inv, yc = y * h_inv;
-    f3 ul = ld3(cam.ul), ur = ld3(cam.ur), bl = ld3(cam.bl), ob = ld3(cam.ob);
-    f3 dir = mk3(xc * (ur.x - ul.x) + yc * (bl.x - ul.x) + ul.x - ob.x,
-                 xc * (ur.y - ul.y) + yc * (bl.y - ul.y) + ul.y - ob.y,
-                 xc * (ur.z - ul.z) + yc * (bl.z - ul.z) + ul.z - ob.z);
-    dir = normalize3(dir);
-    st3(ry.r, dir);
+  f3 dir;
+  const bool pixel = primary_dir(pp, idx, dir);
+  st3(ry.r, dir);
+  if (pixel) {
+    ry.i = 0;
     int i, j, k;
-    if (startup_voxel(g, ob, dir, i, j, k)) { ry.i = i; ry.j = j; ry.k = k; } else ry.i = -1;
+    if (with_voxel) { if (startup_voxel(g, ld3(pp.cam.ob), dir, i, j, k)) { ry.i = i; ry.j = j; ry.k = k; } else ry.i = -1; }
   }
-  rays[idx] = ry;
+  return ry;
+}
+// Start of a chunk: resets its control block (queue lengths, tickets, statistics); n0 rays at level 0.
+__global__ void __launch_bounds__(256) k_chunk_init(int n0, Ctl *__restrict__ ctl) {
+  static_assert(sizeof(Ctl) % 4 == 0 && sizeof(Ctl) / 4 <= 256, "one thread per word of the control block");
+  if (threadIdx.x < sizeof(Ctl) / 4) reinterpret_cast<uint32_t *>(ctl)[threadIdx.x] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) ctl->count[0] = n0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1021,7 +1030,7 @@ __global__ void __launch_bounds__(256) k_primary(CameraD cam, GridP g, int tile0
 // running minimum), and ties keep the lowest triangle index because lists are in ascending order.
 template <bool COUNT>
 __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
-                                                 Ctl *__restrict__ ctl, int level) {
+                                                 Ctl *__restrict__ ctl, int level, PrimaryP prim) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
@@ -1043,7 +1052,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
     const int idx = base + lane;
     Ray ry;
     ry.i = -2;
-    if (idx < nrays) ry = rays[idx];
+    if (idx < nrays) { if (prim.on) ry = primary_ray(prim, g, idx, true); else ry = rays[idx]; }
     bool alive = ry.i >= 0;
     nPixels += __popcll(__ballot(ry.i != -2));
     nTraced += __popcll(__ballot(alive));
@@ -1220,14 +1229,14 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
 __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__restrict__ rays, const Hit *__restrict__ hits,
                                              Node *__restrict__ nodes, const float *__restrict__ geom,
                                              Ray *__restrict__ next_rays, Ctl *__restrict__ ctl, int level,
-                                             int node_base, int next_base, int next_cap, bool spawn) {
+                                             int node_base, int next_base, int next_cap, bool spawn, PrimaryP prim) {
   const int n = ctl->count[level];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = lane_id();
   const bool valid = idx < n;
   Hit h; h.tri = -2;
   Ray ry;
-  if (valid) { h = hits[idx]; ry = rays[idx]; }
+  if (valid) { h = hits[idx]; if (prim.on) ry = primary_ray(prim, g, idx, false); else ry = rays[idx]; }
   Node nd;
   nd.tri = h.tri; nd.refl = -1; nd.refr = -1;
   nd.p[0] = nd.p[1] = nd.p[2] = 0.0f; nd.n[0] = nd.n[1] = nd.n[2] = 0.0f; nd.c[0] = nd.c[1] = nd.c[2] = 0.0f;
@@ -1624,7 +1633,7 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
                                                     const float *__restrict__ ts_in, const int32_t *__restrict__ rand_rank,
                                                     float *__restrict__ colors, Ctl *__restrict__ ctl, int level,
                                                     int node_base, float *__restrict__ fb_rgb, int32_t *__restrict__ fb_ids,
-                                                    long long fb_base, float *__restrict__ partial) {
+                                                    long long fb_base, float *__restrict__ partial, PrimaryP prim) {
   const int n = ctl->count[level];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = idx < n;
@@ -1635,7 +1644,9 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
   f3 res = mk3(0.0f, 0.0f, 0.0f);
   if (nd.tri >= 0) {
     const SurfaceD sf = sp.surf[sp.tri_sid[nd.tri]];
-    const f3 nc = ld3(nd.c), norm = ld3(nd.n), onew = ld3(nd.p), r = ld3(rays[idx].r);
+    const f3 nc = ld3(nd.c), norm = ld3(nd.n), onew = ld3(nd.p);
+    f3 r;
+    if (prim.on) primary_dir(prim, idx, r); else r = ld3(rays[idx].r);
     if (sf.ka > 0.0f) res = mul3(nc, sf.ka * sp.total_flux);
     if (sf.kr > 0.0f) {
       f3 rc = nd.refl >= 0 ? ld3(colors + 4ll * nd.refl) : mk3(0.0f, 0.0f, 0.0f);

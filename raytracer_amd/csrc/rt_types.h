@@ -114,6 +114,10 @@ struct PlanarD { float flux; float color[3]; float a[3], ab[3], ac[3]; };
 
 struct CameraD { float ob[3], ul[3], bl[3], ur[3]; int32_t sw, sh; };
 
+// The primary rays of a chunk of tiles are not stored: the kernels that need one (nearest-hit walk, hit and colour
+// kernels of level 0) compute it from the camera and the ray's index in the chunk.  on = 0: rays come from a queue.
+struct PrimaryP { CameraD cam; int32_t tile0, ntiles, rank, world, tiles_x, on; };
+
 // Scene-wide constants handed to the shading kernels.
 struct ShadeP {
   const SurfaceD *surf;

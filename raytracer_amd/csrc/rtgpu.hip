@@ -92,6 +92,7 @@ struct rtgpu_ctx {
   Hit *d_hits = nullptr;  // sized for the largest level
   Node *d_nodes = nullptr;
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
+  PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
   int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
   Ctl *d_ctl = nullptr;
   unsigned long long *d_totals = nullptr;  // [kStatCount + kMaxLevels + 1]
@@ -210,7 +211,7 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
   c->total_nodes = total;
   int rc;
   for (int L = 0; L < c->levels; L++)
-    if ((rc = dev_alloc(c, &c->d_rays[L], c->cap[L]))) return rc;
+    if ((rc = dev_alloc(c, &c->d_rays[L], L == 0 ? (size_t)1 : c->cap[L]))) return rc;  // (level 0: primary rays are not stored)
   if ((rc = dev_alloc(c, &c->d_hits, maxcap))) return rc;
   if ((rc = dev_alloc(c, &c->d_nodes, total))) return rc;
   if ((rc = dev_alloc(c, &c->d_colors, total * 4))) return rc;
@@ -242,8 +243,8 @@ size_t bytes_per_tile(const rtgpu_ctx *c) {
     nodes += capL;
     maxcap = capL > maxcap ? capL : maxcap;
   }
-  return nodes * (sizeof(Ray) + sizeof(Node) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) +
-         maxcap * sizeof(Hit) + kTilePixels * 4;
+  return nodes * (sizeof(Ray) + sizeof(Node) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) -
+         kTilePixels * sizeof(Ray) + maxcap * sizeof(Hit) + kTilePixels * 4;  // (no ray queue for level 0)
 }
 
 }  // namespace
@@ -570,26 +571,28 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   const int n0 = nt_chunk * kTilePixels;
   const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * RT_WAVES_NEAREST) + 3) / 4);
   const int64_t tx = tiles_x_of(c);
+  c->prim = PrimaryP{c->cam, (int32_t)t0, nt_chunk, rank, world, (int32_t)tx, 1};
+  PrimaryP queued = c->prim;
+  queued.on = 0;
   {
-    Span sp(c, W_PRIMARY);  // (k_primary also resets the control block)
-    hipLaunchKernelGGL(k_primary, dim3((n0 + 255) / 256), dim3(256), 0, c->stream, c->cam, c->grid, (int)t0, nt_chunk, rank, world,
-                       (int)tx, c->d_rays[0], c->d_ctl);
+    Span sp(c, W_PRIMARY);  // the control block; the primary rays themselves are computed where they are used
+    hipLaunchKernelGGL(k_chunk_init, dim3(1), dim3(256), 0, c->stream, n0, c->d_ctl);
   }
   for (int L = 0; L < c->levels; L++) {
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
     {
       Span sp(c, W_NEAREST);
       if (c->opt_count)
-        hipLaunchKernelGGL(k_nearest<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
+        hipLaunchKernelGGL(k_nearest<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
       else
-        hipLaunchKernelGGL(k_nearest<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L);
+        hipLaunchKernelGGL(k_nearest<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
     }
     {
       Span sp(c, W_HIT);
       const bool spawn = L + 1 < c->levels;
       hipLaunchKernelGGL(k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
                          c->d_nodes, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
-                         spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn);
+                         spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn, L == 0 ? c->prim : queued);
     }
   }
   if (c->npl > 0) {
@@ -639,12 +642,15 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
         hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
     }
   }
+  PrimaryP queued = c->prim;
+  queued.on = 0;
   for (int L = c->levels - 1; L >= 0; L--) {
     Span sp(c, W_ACCUM);
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->shade, c->d_rays[L], c->d_nodes,
                        c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
-                       L == 0 ? c->d_partial : nullptr);  // level 0 (the last one) also folds the colour range of its blocks
+                       L == 0 ? c->d_partial : nullptr,  // level 0 (the last one) also folds the colour range of its blocks
+                       L == 0 ? c->prim : queued);
   }
   {
     Span sp(c, W_MINMAX);

@@ -18,7 +18,7 @@ for f in glob.glob(os.path.join(root, "traffic_*", "**", "*counter_collection.cs
         k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("rt::", "").split("<")[0]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"workload": "%s %sx%s" % (scene, w, h), "method": "rocprofv3 --pmc, one counter set per run; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
-for k in ("k_nearest", "k_shadow", "k_hit", "k_accumulate", "k_primary"):
+for k in ("k_nearest", "k_shadow", "k_hit", "k_accumulate"):
     if k not in acc:
         continue
     m = {c: sum(v) / len(v) for c, v in acc[k].items()}
