@@ -24,7 +24,7 @@ $(PKG)/raytrace: $(PKG)/host/main.c $(PKG)/librthost.so
 
 oracle:
 	$(MAKE) -C oracle oracle
-	if [ -d /root/reference/src ]; then $(MAKE) -C oracle ref; fi
+	if [ -d /root/reference/src ]; then $(MAKE) -C oracle ref dropin; fi
 
 clean:
 	rm -f $(PKG)/librtgpu.so $(PKG)/librthost.so $(PKG)/raytrace

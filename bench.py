@@ -15,13 +15,20 @@ metric = Mrays/s, rays counted as the reference issues them (nearest-hit queries
 back-face early-outs included): 40,689,192 per temple 4K frame.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (shadow or nearest walk): algorithmic bytes per launch
-                (64 B per ray + 8 B per visited voxel + 40 B per listed triangle, S and T counted by the
-                kernel's own counting variant in an untimed pass) / its average launch duration from HIP
-                events on the launch stream.  The scene is cache-resident and most listed triangles are
-                rejected a batch at a time, so this logical rate exceeds the HBM peak by a wide margin;
-                `traffic` is what the launch really moved to and from HBM (rocprofv3 counters), and
-                walk_stats says how much of the listed work was executed.
+  roofline      the dominant kernel (shadow or nearest walk) against the bound that holds it, VALU issue: the
+                scene is cache-resident, nothing is a dense contraction, and a SIMD issues one wave64 VALU
+                instruction per two cycles.  frac = 2 x SQ_INSTS_VALU / (cycles x 1024 SIMDs) of one launch,
+                achieved / peak = VALU wave-instructions per second against SIMDs x clock / 2.  Beside it:
+                traffic (HBM bytes per launch from the L2's memory-side counters, corrected as measured on
+                gfx950: 2 x FETCH_SIZE + WRITE_SIZE), hbm_frac (traffic / launch time / 8 TB/s), l2_gbs,
+                l2_hit_rate, flops (45 x exact tests that ran to their last line, per ray) and logical_gbs
+                (64 B per ray + 8 B per visited voxel + 40 B per listed triangle over the launch time: what a
+                walk that read every listed triangle from memory would move; most of it is culled and the rest
+                is served by LDS and L2, so this is no fraction of any peak).  The launch time is measured in
+                this run (HIP events on the launch stream); the counter values come from the rocprofv3 --pmc
+                passes kept under profiles/ (a profiler cannot run inside the timed region), which carry the
+                SHA-256 of raytracer_amd/csrc/* they were collected on: if that differs from this tree's the
+                counter-derived fields are null and "stale" is true.
   cpu_baseline  the unmodified reference (oracle/_ref/ref_dump) or, if that binary is absent, the C
                 oracle, single-threaded on the host, on the same scene at a reduced resolution;
                 cpu_baseline.parallel is the C oracle on the same sample with its rows spread over the
@@ -77,6 +84,104 @@ def cpu_baseline(prefix, over, width, height):
     return out
 
 
+def launch_ranks(args, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: starts N fresh ranks (torch.distributed.run, one process per
+    GPU) as a child of this process, which has touched neither torch nor the GPU, relays rank 0's JSON line and
+    returns the child's exit status."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        print(lines[-1], flush=True)
+    if child.returncode != 0:
+        sys.stderr.write("bench.py: the %d-rank run ended with status %d\n" % (args.gpus, child.returncode))
+        return child.returncode
+    if not lines:
+        sys.stderr.write("bench.py: the %d-rank run printed no result line\n" % args.gpus)
+        return 1
+    return 0
+
+
+def counter_profile(fam):
+    """Counter values of one launch of k_<fam> from the rocprofv3 passes kept under profiles/ (SQ counters in pmc.json,
+    L2 memory-side counters in traffic.json), or None for a file that is missing or was collected on other kernel
+    sources than this tree's."""
+    import raytracer_amd as rt
+    have = rt.csrc_hash()
+    out = {}
+    for key, name in (("pmc", "pmc.json"), ("traffic", "traffic.json")):
+        out[key] = None
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if j.get("csrc_sha256") == have and ("k_" + fam) in j:
+            out[key] = dict(j["k_" + fam], workload=j.get("workload"))
+    return out
+
+
+def roofline(fam, avg_ms, q, S, T, full_tests, lane_slots, workload):
+    """The roofline object of the dominant walk kernel (see the module docstring)."""
+    secs = avg_ms * 1e-3
+    prof = counter_profile(fam)
+    pm, tr = prof["pmc"], prof["traffic"]
+    # the counters describe whole-frame launches of the default workload on one GPU
+    if pm is not None and pm.get("workload") != workload:
+        pm = None
+    if tr is not None and tr.get("workload") != workload:
+        tr = None
+    out = {"bound": "valu_issue", "kernel": "k_" + fam, "achieved": None, "peak": None, "unit": "G wave-instructions/s",
+           "frac": None, "traffic": None, "hbm_frac": None, "hbm_gbs": None, "l2_gbs": None, "l2_hit_rate": None,
+           "avg_launch_ms": round(avg_ms, 4), "stale": pm is None or tr is None}
+    if pm is not None and secs > 0:
+        simds = 1024.0                                   # 256 CUs x 4 SIMDs
+        cycles = pm.get("GRBM_GUI_ACTIVE", 0.0) / 8.0    # the counter is summed over the 8 XCDs
+        valu = pm.get("SQ_INSTS_VALU", 0.0)
+        insts = sum(pm.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS",
+                                               "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"))
+        if cycles > 0 and valu > 0:
+            clock_ghz = cycles / secs / 1e9              # the clock this run held, from the profiled cycle count
+            out["achieved"] = round(valu / secs / 1e9, 2)
+            out["peak"] = round(simds * clock_ghz / 2.0, 2)   # one wave64 VALU instruction per SIMD per two cycles
+            out["frac"] = round(2.0 * valu / (cycles * simds), 4)
+            out["issue"] = {"wave_instructions_per_launch": int(insts), "cycles_per_launch": int(cycles),
+                            "valu_share": round(valu / insts, 3),
+                            "salu_branch_share": round((pm.get("SQ_INSTS_SALU", 0.0) + pm.get("SQ_INSTS_BRANCH", 0.0)) / insts, 3),
+                            "lds_share": round(pm.get("SQ_INSTS_LDS", 0.0) / insts, 3),
+                            "cycles_per_instruction_per_simd": round(cycles * simds / insts, 3),
+                            "resident_waves_per_simd": round(pm.get("SQ_WAVES", 0.0) / simds, 2)}
+    if tr is not None and secs > 0:
+        hbm = tr.get("hbm_bytes_per_launch")
+        if hbm:
+            out["traffic"] = int(hbm)
+            out["hbm_gbs"] = round(hbm / secs / 1e9, 1)
+            out["hbm_frac"] = round(hbm / secs / 1e9 / HBM_PEAK_GBS, 4)
+        req = tr.get("l2_requests_per_launch")
+        if req:
+            out["l2_gbs"] = round(req * 64.0 / secs / 1e9, 1)   # a vector-cache request to L2 carries 64 B
+        if tr.get("l2_hit_rate") is not None:
+            out["l2_hit_rate"] = round(tr["l2_hit_rate"], 4)
+    alg_bytes = 64.0 * q + 8.0 * S + 40.0 * T
+    out["flops"] = int(45 * full_tests)
+    out["gflops"] = round(45.0 * full_tests / secs / 1e9, 2) if secs > 0 else None
+    out["logical_gbs"] = round(alg_bytes / secs / 1e9, 1) if secs > 0 else None
+    out["algorithmic_bytes_per_launch"] = int(alg_bytes)
+    out["listed_tests_per_launch"] = int(T)
+    out["executed_tests_frac"] = round(lane_slots / T, 4) if T else None
+    out["source"] = ("launch time: HIP events of this run; SQ / L2 counters: rocprofv3 --pmc passes under profiles/ on the same "
+                     "kernel sources (csrc_sha256), null when stale")
+    out["note"] = ("instruction-issue bound: frac is the share of SIMD cycles that issue a VALU instruction; HBM sees hbm_frac "
+                   "of its peak; logical_gbs counts every listed triangle as if read from memory and is no fraction of a peak")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +194,13 @@ def main():
     ap.add_argument("--cpu-width", type=int, default=960)
     ap.add_argument("--cpu-height", type=int, default=540)
     args = ap.parse_args()
+
+    # Before anything touches torch or the GPU: a plain `python bench.py --gpus N` starts its own ranks.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%s but --gpus %d" % (os.environ["WORLD_SIZE"], args.gpus))
 
     # Libraries below write banners to the C-level stdout (RCCL prints its version when a communicator is made); the
     # one JSON line is the only thing this program may print there, so stdout points to stderr until that line.
@@ -104,9 +216,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force = world == 1 and os.environ.get("RTGPU_BENCH_FORCE_COLLECTIVES") == "1"  # rehearsal of the N > 1 code on one GPU
@@ -169,38 +278,10 @@ def main():
         else:
             q, S, T = cnt["nearest_queries"], cnt["nearest_steps"], cnt["nearest_tests"]
         per_launch = args.steps / launches  # frames per launch of this family (1 when the frame is one chunk)
-        alg_bytes = (64.0 * q + 8.0 * S + 40.0 * T) * per_launch
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, l2_hit = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile) and world == 1:  # (the counters were collected on whole-frame launches)
-            try:
-                tj = json.load(open(tfile)).get("k_" + fam, {})
-                traffic = tj.get("hbm_bytes_per_launch")
-                l2_hit = tj.get("l2_hit_rate")
-            except Exception:
-                traffic = None
-        # what really bounds the kernel: instruction issue.  Wave-instructions and cycles of one launch from the SQ
-        # counters of the last profiled run (profiles/pmc.json); the machine's rate from tools/micro/issue_rate.hip.
-        issue = None
-        pfile = os.path.join(ROOT, "profiles", "pmc.json")
-        if os.path.exists(pfile) and world == 1:
-            try:
-                pm = json.load(open(pfile)).get("k_" + fam, {})
-                insts = sum(pm.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"))
-                cycles = pm.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
-                if insts > 0 and cycles > 0:
-                    cpi = cycles * 1024.0 / insts  # 256 CUs x 4 SIMDs
-                    waves = pm.get("SQ_WAVES", 0.0)
-                    issue = {"wave_instructions_per_launch": int(insts), "cycles_per_launch": int(cycles),
-                             "valu_share_of_instructions": round(pm.get("SQ_INSTS_VALU", 0.0) / insts, 3),
-                             # a wave64 VALU instruction occupies the 32-lane SIMD for two cycles
-                             "valu_busy_frac": round(2.0 * pm.get("SQ_INSTS_VALU", 0.0) / (cycles * 1024.0), 3),
-                             "resident_waves_per_simd": round(waves / 1024.0, 2) if waves else None,
-                             "cycles_per_instruction_per_simd": round(cpi, 3), "machine_cycles_per_instruction": 2.1,
-                             "frac": round(2.1 / cpi, 3), "source": "profiles/pmc.json (rocprofv3 --pmc of an earlier run of this workload)"}
-            except Exception:
-                issue = None
+        full = cnt[fam + "_full_tests"]
+        workload = "%s %dx%d" % (args.scene, args.width, args.height)
+        roof = roofline(fam, avg_ms, q * per_launch, S * per_launch, T * per_launch, full * per_launch,
+                        cnt[fam + "_lane_slots"] * per_launch, workload if world == 1 else None)
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": round(rays_frame * args.steps / elapsed / 1e6, 3),
             "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,16 +295,7 @@ def main():
             "kernel_ms_per_frame_rank0": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
             "kernel_ms_note": "HIP events on the stream each kernel runs on; preprocess_ms and grid_ms are elapsed on the build "
                               "stream, where the set-up of frame k+1 overlaps the walk kernels of frame k (alone it takes 0.27 ms)",
-            "roofline": {"bound": "hbm", "kernel": "k_" + fam, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "hbm_gbs_measured": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
-                         "l2_hit_rate": round(l2_hit, 4) if l2_hit is not None else None,
-                         "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "listed_tests_per_launch": int(T * per_launch),
-                         "executed_tests_frac": round(cnt[fam + "_lane_slots"] / T, 4) if T else None,
-                         "note": "logical bytes (64 B/ray + 8 B/voxel + 40 B/listed triangle); the scene is cache-resident and "
-                                 "batches of listed triangles are culled, so frac exceeds 1 without touching HBM; the kernel is "
-                                 "bound by instruction issue (see profiles/)", "issue": issue},
+            "roofline": roof,
         }
         def ratio(a, b):
             return round(a / b, 4) if b else None

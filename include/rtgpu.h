@@ -104,9 +104,12 @@ typedef struct rtgpu_counters {
   int64_t nearest_stage2, nearest_stage3, nearest_exact, shadow_stage2, shadow_stage3, shadow_exact;
   /* Cell visits of the wavefronts: iterations of the walk kernels' outer loop (only with "count" = 1). */
   int64_t nearest_visits, shadow_visits;
-  /* Batches of 16 listed triangles the cell-mode walks looked at, and how many of them were skipped because
+  /* Batches of 8 listed triangles the cell-mode walks looked at, and how many of them were skipped because
    * no ray of the wavefront could meet the batch's bounding box (only with "count" = 1). */
   int64_t nearest_batches, nearest_batches_culled, shadow_batches, shadow_batches_culled;
+  /* Exact tests (src/intersection.c:58-86) that ran to their last line, counted per ray (lane), not per wavefront:
+   * 45 flops each in the reference's accounting (only with "count" = 1). */
+  int64_t nearest_full_tests, shadow_full_tests;
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP
@@ -134,7 +137,8 @@ int rtgpu_set_stream(rtgpu_ctx *ctx, void *hip_stream);
 int rtgpu_set_null_stream(rtgpu_ctx *ctx);
 
 /* Options: "count" (0/1) S/T counters, "timing" (0/1) per-kernel events, "chunk_bytes" (device
- * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default: what each walk kernel is compiled for, 20 and 24), "pipeline" (default 1: rtgpu_frame_begin builds on its
+ * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default:
+ * what each walk kernel is compiled for, 20 and 24), "pipeline" (default 1: rtgpu_frame_begin builds on its
  * own stream into the buffers the previous frame does not use, overlapping that frame's kernels; 0: on the context's stream),
  * "filter" (default 1; 0 switches off the conservative triangle filter and the batch culling of the
  * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */
@@ -154,6 +158,10 @@ int rtgpu_grid_info_get(const rtgpu_ctx *ctx, rtgpu_grid_info *out);
  * owns tiles r, r+world, r+2*world, ...  Tile-major buffers hold 64 pixels per owned tile (pixel
  * (x,y) of a tile at slot (y&7)*8 + (x&7)); slots outside the image are padding. */
 int64_t rtgpu_tile_count(const rtgpu_ctx *ctx, int rank, int world);
+/* No counterpart in the reference (it has no queues): the largest number of tiles rtgpu_render traces in one chunk,
+ * whatever "chunk_bytes" allows, for a scene whose hits spawn up to `fan` secondary rays over `levels` recursion levels
+ * with `nslots` shadow queries per hit: node indices are 32-bit and so are the tickets of the walk kernels.  Needs no GPU. */
+int64_t rtgpu_chunk_tile_limit(int fan, int levels, int nslots);
 
 /* The pixel loop (src/raytrace.c:371-404) for the tiles of `rank`.
  *   d_rgb    : tile_count*64*3 floats, raw colour (RT_VisualizedScenePixel.c), 0 where the reference leaves the pixel unwritten

@@ -1,0 +1,172 @@
+/* Drop-in replacement for the reference's src/raytrace.c: the same three entry points
+ *     rtVisualizedSceneRaytrace / rtVisualizedSceneDestroy / rtVisualizedSceneToBitmap   (src/raytrace.h:57-64)
+ * with the per-pixel trace path and the tone map running on the GPU through librtgpu (include/rtgpu.h).
+ *
+ * This file is compiled against the reference's OWN headers (-I<reference>/src: scene.h, raytrace.h, bitmap.h,
+ * preprocess.h, error.h) and linked with the reference's unmodified main.o, scene.o, bitmap.o, error.o,
+ * stringtools.o, preprocess.o, intersection.o in place of raytrace.o, voxelize.o and texture.o:
+ *     gcc -std=gnu11 -O2 -I<reference>/src -I<this repo>/include -c integration/raytrace_gpu.c
+ *     gcc -o raytrace main.o scene.o bitmap.o error.o stringtools.o preprocess.o intersection.o raytrace_gpu.o \
+ *         -L<this repo>/raytracer_amd -lrtgpu -lm
+ * What stays on the host is what the reference does on the host before its pixel loop and what its callers read
+ * afterwards: rtScenePreprocess (the texture on/off switch, src/preprocess.c:13,41-79; its per-triangle results are
+ * left in RT_Scene as the reference leaves them), the grown scene domain, min/max and the pixel map.
+ *
+ * Environment: RTGPU_DEVICE selects the GPU (default 0).  Errors follow the reference's convention: errno is set to
+ * one of its codes (src/error.h:19-42) and NULL is returned.
+ */
+#include <errno.h>
+#include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "raytrace.h"
+#include "preprocess.h"
+#include "error.h"
+#include "rtgpu.h"
+
+static rtgpu_ctx *g_ctx; /* one context per process and GPU, created at the first frame */
+
+static rtgpu_ctx *context(void) {
+  if (!g_ctx) {
+    const char *dev = getenv("RTGPU_DEVICE");
+    int rc = rtgpu_create(dev ? atoi(dev) : 0, &g_ctx);
+    if (rc) {
+      fprintf(stderr, "rtgpu: %s (the trace path has no CPU implementation)\n", rtgpu_error_string(rc));
+      errno = rc <= E_INVALID_PARAM_VALUE ? rc : E_IO;
+      return NULL;
+    }
+  }
+  return g_ctx;
+}
+
+static int gpu_failed(rtgpu_ctx *ctx, int rc) {
+  if (rc) {
+    fprintf(stderr, "rtgpu: %s: %s\n", rtgpu_error_string(rc), rtgpu_last_message(ctx));
+    errno = rc <= E_INVALID_PARAM_VALUE ? rc : E_INVALID_PARAM_VALUE;
+  }
+  return rc;
+}
+
+RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera) {
+  const size_t np = (size_t)camera->sw * (size_t)camera->sh;
+  const int32_t nt = scene->nt, ns = scene->ns, nl = scene->nl, npl = scene->npl;
+  RT_VisualizedScene *res = calloc(1, sizeof *res);
+  float *verts = NULL, *rgb = NULL, mm[6];
+  int32_t *sid = NULL, *ids = NULL;
+  rtgpu_surface *surf = NULL;
+  rtgpu_light *lgt = NULL;
+  rtgpu_planar_light *pl = NULL;
+  rtgpu_scene_desc d;
+  rtgpu_camera cam;
+  rtgpu_grid_info gi;
+  rtgpu_ctx *ctx;
+  int32_t i;
+  int k, ok = 0, saved;
+  size_t p;
+
+  if (!res || !(res->map = calloc(np ? np : 1, sizeof *res->map))) { errno = E_MEMORY; goto out; }
+  res->width = camera->sw;
+  res->height = camera->sh;
+  res->gamma = scene->cfg.gamma > 0.0f ? scene->cfg.gamma : 2.5f; /* src/raytrace.c:333-337 */
+
+  /* host side of the frame: the reference's own preprocess (texture switch; n, ij, ik, d stay in RT_Scene) */
+  rtScenePreprocess(scene, camera);
+
+  /* RT_Scene / RT_Camera -> plain arrays */
+  verts = malloc(sizeof(float) * 9 * (size_t)(nt > 0 ? nt : 1));
+  sid = malloc(sizeof(int32_t) * (size_t)(nt > 0 ? nt : 1));
+  surf = calloc((size_t)ns + 1, sizeof *surf);
+  lgt = calloc((size_t)nl + 1, sizeof *lgt);
+  pl = calloc((size_t)npl + 1, sizeof *pl);
+  rgb = malloc(sizeof(float) * 3 * (np ? np : 1));
+  ids = malloc(sizeof(int32_t) * (np ? np : 1));
+  if (!verts || !sid || !surf || !lgt || !pl || !rgb || !ids) { errno = E_MEMORY; goto out; }
+  memset(&d, 0, sizeof d);
+  for (i = 0; i < nt; i++) {
+    const RT_Triangle *t = &scene->t[i];
+    for (k = 0; k < 3; k++) { verts[9 * i + k] = t->i[k]; verts[9 * i + 3 + k] = t->j[k]; verts[9 * i + 6 + k] = t->k[k]; }
+    sid[i] = t->sid;
+    if (t->texture) d.texture_present = 1;
+  }
+  for (i = 0; i < ns; i++) {
+    const RT_Surface *s = &scene->s[i];
+    for (k = 0; k < 3; k++) surf[i].color[k] = s->color.c[k];
+    surf[i].kd = s->kd; surf[i].ks = s->ks; surf[i].g = s->g; surf[i].ka = s->ka;
+    surf[i].kt = s->kt; surf[i].eta = s->eta; surf[i].kr = s->kr;
+  }
+  for (i = 0; i < nl; i++) {
+    const RT_Light *l = &scene->l[i];
+    for (k = 0; k < 3; k++) { lgt[i].p[k] = l->p[k]; lgt[i].color[k] = l->color.c[k]; }
+    lgt[i].flux = l->flux;
+  }
+  for (i = 0; i < npl; i++) {
+    const RT_PlanarLight *q = &scene->pl[i];
+    pl[i].flux = q->flux;
+    for (k = 0; k < 3; k++) { pl[i].color[k] = q->color.c[k]; pl[i].a[k] = q->a[k]; pl[i].ab[k] = q->ab[k]; pl[i].ac[k] = q->ac[k]; }
+  }
+  d.nt = nt; d.ns = ns; d.nl = nl; d.npl = npl;
+  d.vertices = verts; d.sid = sid; d.surfaces = surf; d.lights = lgt; d.planar = pl;
+  for (k = 0; k < 3; k++) { d.dmin[k] = scene->dmin[k]; d.dmax[k] = scene->dmax[k]; d.vcoeff[k] = scene->cfg.vcoeff[k]; }
+  d.gamma = scene->cfg.gamma; d.distmod = scene->cfg.distmod; d.vmode = (int32_t)scene->cfg.vmode;
+  for (k = 0; k < 3; k++) { cam.ob[k] = camera->ob[k]; cam.ul[k] = camera->ul[k]; cam.bl[k] = camera->bl[k]; cam.ur[k] = camera->ur[k]; }
+  cam.sw = camera->sw; cam.sh = camera->sh;
+
+  /* the GPU does what src/raytrace.c:346-404 does.  The GPU runtime may leave stray errno values (ENOENT, EAGAIN ...)
+   * on paths that worked, and the caller reads errno (src/main.c:190): keep the value the host code had. */
+  saved = errno;
+  if (!(ctx = context())) goto out;
+  if (gpu_failed(ctx, rtgpu_scene_upload(ctx, &d))) goto out;
+  if (gpu_failed(ctx, rtgpu_frame_begin(ctx, &cam))) goto out;
+  if (gpu_failed(ctx, rtgpu_render_host(ctx, rgb, ids, mm))) goto out;
+  if (gpu_failed(ctx, rtgpu_grid_info_get(ctx, &gi))) goto out;
+  errno = saved;
+
+  /* results into the reference's structures */
+  res->total_flux = gi.total_flux;
+  for (k = 0; k < 3; k++) {
+    res->min.c[k] = mm[k]; res->max.c[k] = mm[3 + k];
+    scene->dmin[k] = gi.dmin[k]; scene->dmax[k] = gi.dmax[k]; /* the reference grows the domain in place (src/raytrace.c:350-353, src/voxelize.c:140-141) */
+  }
+  res->min.c[3] = FLT_MAX; res->max.c[3] = FLT_MIN; /* src/raytrace.c:317-320: the alpha lane is never updated */
+  for (p = 0; p < np; p++) {
+    res->map[p].c.c[0] = rgb[3 * p]; res->map[p].c.c[1] = rgb[3 * p + 1]; res->map[p].c.c[2] = rgb[3 * p + 2];
+    res->map[p].t = ids[p] >= 0 ? &scene->t[ids[p]] : NULL;
+  }
+  ok = 1;
+out:
+  free(verts); free(sid); free(surf); free(lgt); free(pl); free(rgb); free(ids);
+  if (!ok) rtVisualizedSceneDestroy(&res);
+  return res;
+}
+
+void rtVisualizedSceneDestroy(RT_VisualizedScene **self) {
+  if (self && *self) { free((*self)->map); free(*self); *self = NULL; }
+}
+
+RT_Bitmap *rtVisualizedSceneToBitmap(RT_VisualizedScene *s, int flags, void *param1) {
+  const size_t np = (size_t)s->width * (size_t)s->height;
+  RT_Bitmap *bmp = rtBitmapCreate(s->width, s->height, 0);
+  rtgpu_ctx *ctx;
+  float *rgb, mm[6], gamma = s->gamma;
+  size_t p;
+  int k, saved;
+  if (!bmp) return NULL;
+  if (!(flags & F_HDR)) return bmp; /* src/raytrace.c:437: nothing is drawn without F_HDR */
+  if (param1) { /* zero-terminated gamma list (src/raytrace.c:439-447); the GPU tone map takes one gamma */
+    const float *g = param1;
+    if (!(g[0] > 0.0f) || g[1] > 0.0f) { errno = E_INVALID_PARAM_VALUE; rtBitmapDestroy(&bmp); return NULL; }
+    gamma = g[0];
+  }
+  saved = errno;
+  if (!(ctx = context())) { rtBitmapDestroy(&bmp); return NULL; }
+  rgb = malloc(sizeof(float) * 3 * (np ? np : 1));
+  if (!rgb) { errno = E_MEMORY; rtBitmapDestroy(&bmp); return NULL; }
+  for (p = 0; p < np; p++) for (k = 0; k < 3; k++) rgb[3 * p + k] = s->map[p].c.c[k];
+  for (k = 0; k < 3; k++) { mm[k] = s->min.c[k]; mm[3 + k] = s->max.c[k]; }
+  if (gpu_failed(ctx, rtgpu_tonemap_host(ctx, rgb, (int64_t)np, mm, gamma, bmp->pixels))) rtBitmapDestroy(&bmp);
+  else errno = saved;
+  free(rgb);
+  return bmp;
+}

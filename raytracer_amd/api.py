@@ -58,7 +58,8 @@ class Counters(C.Structure):
                                          "nearest_lane_tests", "nearest_lane_slots", "shadow_lane_tests",
                                          "shadow_lane_slots", "nearest_stage2", "nearest_stage3", "nearest_exact",
                                          "shadow_stage2", "shadow_stage3", "shadow_exact", "nearest_visits", "shadow_visits", "nearest_batches",
-                                         "nearest_batches_culled", "shadow_batches", "shadow_batches_culled")]
+                                         "nearest_batches_culled", "shadow_batches", "shadow_batches_culled",
+                                         "nearest_full_tests", "shadow_full_tests")]
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -81,6 +82,19 @@ class Timings(C.Structure):
 class SceneFlat(C.Structure):
     _fields_ = [("desc", SceneDesc), ("vertices", C.POINTER(C.c_float)), ("sid", C.POINTER(C.c_int32)),
                 ("surfaces", C.POINTER(Surface)), ("lights", C.POINTER(Light)), ("planar", C.POINTER(PlanarLight))]
+
+
+def csrc_hash():
+    """SHA-256 over the names and contents of the kernel sources (raytracer_amd/csrc/*): what counter profiles are
+    stamped with, so that a reader can tell whether they describe the kernels of this tree."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode() + b"\0")
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 # ---- library loading --------------------------------------------------------------------------
@@ -360,6 +374,7 @@ class Renderer:
         w, h = self.camera.sw, self.camera.sh
         row = int(self._L.rtgpu_bmp_row_bytes(w, bpp))
         rows = torch.empty(row * h, dtype=torch.uint8, device=image.device)
+        torch.cuda.synchronize(image.device)  # `image` may still be in flight on torch's stream; the context has its own
         self.bmp_rows(image, bpp, rows)
         self.sync()
         hdr = (C.c_ubyte * 54)()

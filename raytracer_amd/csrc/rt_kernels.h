@@ -1,9 +1,10 @@
 // HIP kernels of the trace path (gfx950, wave64).  Included once by rtgpu.hip.
 //
-// Frame set-up          k_preprocess, k_tri_boxes, k_grid_offsets, k_grid_fill
-// Pixel loop (a chunk)  k_chunk_init -> [k_nearest -> k_hit] per recursion level -> k_shadow per level
+// Frame set-up          k_preprocess, k_tri_boxes -> k_grid_offsets -> k_grid_fill -> k_grid_sort -> k_grid_bounds
+// Pixel loop (a chunk)  k_chunk_init -> [k_nearest -> k_hit] per recursion level (level 0 computes its primary rays)
+//                       [-> k_subtree_hits, k_tree_starts, k_assign_ranks with planar lights] -> k_shadow per level
 //                       -> k_accumulate per level, deepest first (level 0 folds the colour range of its blocks) -> k_minmax_final
-// After the exchange    k_tonemap, k_untile
+// After the exchange    k_tonemap, k_untile, k_bmp_rows
 #pragma once
 #include "rt_math.h"
 #include "rt_texture.h"
@@ -454,9 +455,9 @@ RT_D RecB rec_b(const float *R) {
 }
 RT_D int rec_id(const float *R) { return __float_as_int(R[10]); }
 // The exact test of a triangle the filter could not decide: i, ij, ik by index.
-RT_D bool exact_test(const GridP &g, int id, f3 o, f3 r, float &d, float &u, float &v) {
+RT_D bool exact_test(const GridP &g, int id, f3 o, f3 r, float &d, float &u, float &v, bool *full = nullptr) {
   const float *G = g.geom + 9 * (long long)id;
-  return tri_test(ld3(G), ld3(G + 3), ld3(G + 6), o, r, d, u, v);
+  return tri_test(ld3(G), ld3(G + 3), ld3(G + 6), o, r, d, u, v, full);
 }
 
 // What one nearest-hit test concludes from the later stages, for a lane that passed the first slab.
@@ -1020,14 +1021,16 @@ __global__ void __launch_bounds__(256) k_chunk_init(int n0, Ctl *__restrict__ ct
 // ------------------------------------------------------------------------------------------------
 // Nearest-hit walk (voxelize.c:536-613) as a persistent wavefront kernel.
 //
-// Each wavefront draws batches of 64 rays from a ticket counter; one lane owns one ray and runs the
-// reference's 3D-DDA for it.  The triangle tests are organised per CELL, not per lane: the wavefront
-// picks the cell of its first unfinished lane, every lane currently standing in that cell joins, and
-// the cell's packed triangle list is streamed once through wave-uniform (scalar) loads while the
-// joined lanes evaluate Möller–Trumbore against SGPR operands.  Lanes in other cells wait their turn.
-// A lane that found a hit inside the voxel's exit distance retires; otherwise it steps its DDA to the
-// next non-empty cell.  All triangles of a visited cell are tested (the reference's test ignores the
-// running minimum), and ties keep the lowest triangle index because lists are in ascending order.
+// Each wavefront draws tickets of 64 rays from a counter (Tickets); one lane owns one ray and runs the
+// reference's 3D-DDA for it (Walk).  The triangle tests are organised per visit, not per lane: the wavefront
+// picks the cell of its least advanced unfinished lane and one of three modes (pick_mode).  In cell mode
+// every lane standing in that cell joins, the cell's batch headers and the records of the batches that
+// survive the culling are staged in LDS (stream_cell) and every joined lane tests every staged record with
+// the staged filter, tri_test deciding what the filter cannot; lane mode and ray mode read the records from
+// memory.  A lane that found a hit before the voxel's exit distance retires; otherwise it steps to its next
+// non-empty cell.  Every listed triangle of a visited cell is accounted for (tested, or proven irrelevant by
+// the culling), and of equal distances the smallest triangle index wins, as in the reference's scan of its
+// ascending list.
 template <bool COUNT>
 __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
                                                  Ctl *__restrict__ ctl, int level, PrimaryP prim) {
@@ -1039,7 +1042,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
   const int nrays = ctl->count[level];
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
-  unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
+  unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0, nFull = 0;
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
   Phases ph;
   ph.begin();
@@ -1113,7 +1116,9 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
             float d, u, v;
             // the reference keeps the first of equal distances in its ascending list = the smallest triangle index; written
             // on the index, the choice does not depend on the order the list is walked in (bid = -1: the voxel's exit distance)
-            if (exact_test(g, id, to, tr, d, u, v) && id != cur && (d < b || (d == b && id < bid))) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
+            bool full = false;
+            if (exact_test(g, id, to, tr, d, u, v, COUNT ? &full : nullptr) && id != cur && (d < b || (d == b && id < bid))) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
+            if (COUNT && full) nFull++;
           }
         }
       };
@@ -1210,11 +1215,12 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
     // wave-level sums, one atomic per counter per wavefront
     for (int off = 32; off > 0; off >>= 1) {
       nS += __shfl_down(nS, off); nT += __shfl_down(nT, off); nLane += __shfl_down(nLane, off); nQ += __shfl_down(nQ, off);
+      nFull += __shfl_down(nFull, off);
     }
     if (lane == 0) {
       atomicAdd(&ctl->stat[kNearS], nS); atomicAdd(&ctl->stat[kNearT], nT);
       atomicAdd(&ctl->stat[kNearLaneTests], nLane); atomicAdd(&ctl->stat[kNearWaveTests], nWave * 64ull);
-      atomicAdd(&ctl->stat[kNearestQ], nQ);
+      atomicAdd(&ctl->stat[kNearestQ], nQ); atomicAdd(&ctl->stat[kNearFull], nFull);
       atomicAdd(&ctl->stat[kNearStage2], nS2); atomicAdd(&ctl->stat[kNearStage3], nS3); atomicAdd(&ctl->stat[kNearExact], nEx);
       atomicAdd(&ctl->stat[kNearVisits], nVisit); atomicAdd(&ctl->stat[kNearBatches], nBatch); atomicAdd(&ctl->stat[kNearCulled], nCull);
     }
@@ -1396,7 +1402,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   const long long total = (long long)n * sp.nslots;
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
-  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0;
+  unsigned long long nS = 0, nT = 0, nQ = 0, nW = 0, nLane = 0, nWave = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0, nFull = 0;
   Phases ph;
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
@@ -1491,7 +1497,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
               verdict = 0;
             } else if (verdict == 1) {
               float d, u, v;
-              verdict = !exact_test(g, id, to, tr, d, u, v) ? 0 : kt > 0.0f ? 2 : (d > 0.00001f && d < tdmax) ? 3 : 0;
+              bool full = false;
+              verdict = !exact_test(g, id, to, tr, d, u, v, COUNT ? &full : nullptr) ? 0 : kt > 0.0f ? 2 : (d > 0.00001f && d < tdmax) ? 3 : 0;
+              if (COUNT && full) nFull++;
             }
           }
           react(verdict, kt);
@@ -1588,9 +1596,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       nS += __shfl_down(nS, off); nT += __shfl_down(nT, off); nQ += __shfl_down(nQ, off); nW += __shfl_down(nW, off);
-      nLane += __shfl_down(nLane, off);
+      nLane += __shfl_down(nLane, off); nFull += __shfl_down(nFull, off);
     }
     if (lane == 0) {
+      atomicAdd(&ctl->stat[kShadFull], nFull);
       atomicAdd(&ctl->stat[kShadLaneTests], nLane); atomicAdd(&ctl->stat[kShadWaveTests], nWave * 64ull);
       atomicAdd(&ctl->stat[kShadS], nS); atomicAdd(&ctl->stat[kShadT], nT);
       atomicAdd(&ctl->stat[kShadowQ], nQ); atomicAdd(&ctl->stat[kShadowWalks], nW);
@@ -1751,7 +1760,7 @@ __global__ void __launch_bounds__(1024) k_minmax_final(const float *__restrict__
 __global__ void k_frame_init(float *minmax, unsigned long long *totals) {
   if (threadIdx.x < 3) minmax[threadIdx.x] = FLT_MAX;       // raytrace.c:318
   else if (threadIdx.x < 6) minmax[threadIdx.x] = FLT_MIN;  // raytrace.c:319 (smallest positive normal, as written)
-  if (threadIdx.x < 32) totals[threadIdx.x] = 0ull;
+  if (threadIdx.x < kTotals) totals[threadIdx.x] = 0ull;
 }
 __global__ void k_minmax_init(float *minmax) {
   if (threadIdx.x < 3) minmax[threadIdx.x] = FLT_MAX;       // raytrace.c:318

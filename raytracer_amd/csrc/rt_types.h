@@ -137,11 +137,13 @@ struct Ctl {
   uint32_t ticket_nearest[kMaxLevels];
   uint32_t ticket_shadow[kMaxLevels];
   uint32_t pad;
-  unsigned long long stat[28];
+  unsigned long long stat[32];
 };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
             kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests,
             kNearStage2, kNearStage3, kNearExact, kShadStage2, kShadStage3, kShadExact,
-            kNearVisits, kShadVisits, kNearBatches, kNearCulled, kShadBatches, kShadCulled, kStatCount };
+            kNearVisits, kShadVisits, kNearBatches, kNearCulled, kShadBatches, kShadCulled, kNearFull, kShadFull, kStatCount };
+constexpr int kTotals = 40;  // frame totals: kStatCount counters, then the queue length of every level
+static_assert(kStatCount <= 32 && kStatCount + kMaxLevels <= kTotals, "the statistics fit the control block and the totals buffer");
 
 }  // namespace rt

@@ -118,6 +118,15 @@ int fail(rtgpu_ctx *c, int code, const std::string &m) {
                   std::string(#expr) + ": " + hipGetErrorString(e_));                              \
   } while (0)
 
+// A kernel launch whose failure (bad configuration, no code object for this GPU, ...) is reported with the kernel's name.
+#define KLAUNCH(ctx, kern, grid, block, st, ...)                                                   \
+  do {                                                                                             \
+    hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);                                     \
+    hipError_t e_ = hipGetLastError();                                                             \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(ctx, RTGPU_E_NO_DEVICE, std::string("launch of " #kern ": ") + hipGetErrorString(e_)); \
+  } while (0)
+
 template <typename T>
 int dev_alloc(rtgpu_ctx *c, T **p, size_t n) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -289,7 +298,7 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
   if (hipMalloc((void **)&c->d_ctl, sizeof(Ctl)) != hipSuccess ||
-      hipMalloc((void **)&c->d_totals, sizeof(unsigned long long) * 32) != hipSuccess ||
+      hipMalloc((void **)&c->d_totals, sizeof(unsigned long long) * kTotals) != hipSuccess ||
       hipMalloc((void **)&c->d_partial, sizeof(float) * 6 * kPartialBlocks) != hipSuccess) {
     rtgpu_destroy(c);
     return RTGPU_E_MEMORY;
@@ -482,15 +491,15 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
     Span sp(c, W_PRE, bs);
-    hipLaunchKernelGGL(k_preprocess, dim3(tblocks), dim3(tb), 0, bs, c->nt, c->d_verts, f3{cam->ob[0], cam->ob[1], cam->ob[2]}, c->d_sid, c->d_surf,
+    KLAUNCH(c, k_preprocess, dim3(tblocks), dim3(tb), bs, c->nt, c->d_verts, f3{cam->ob[0], cam->ob[1], cam->ob[2]}, c->d_sid, c->d_surf,
                        c->d_geom, c->d_aux, c->d_filt);
   }
   uint32_t nrefs = 0;
   {
     Span sp(c, W_GRID, bs);
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(uint32_t) * ((size_t)ncells + 1), bs));
-    hipLaunchKernelGGL(k_tri_boxes, dim3(tblocks), dim3(tb), 0, bs, c->nt, c->d_verts, g, c->d_box, c->d_counts);
-    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(1024), 0, bs, ncells, nv[1], nv[2], c->d_counts, c->d_cell_start, c->d_hdr_start, c->d_nbatch, c->d_occ,
+    KLAUNCH(c, k_tri_boxes, dim3(tblocks), dim3(tb), bs, c->nt, c->d_verts, g, c->d_box, c->d_counts);
+    KLAUNCH(c, k_grid_offsets, dim3(1), dim3(1024), bs, ncells, nv[1], nv[2], c->d_counts, c->d_cell_start, c->d_hdr_start, c->d_nbatch, c->d_occ,
                        reinterpret_cast<int32_t *>(c->d_occ + ((size_t)ncells / 32 + 1)));
     // The grid depends on the scene and its lights only, so the numbers of references and of non-empty cells are
     // read back (a host sync) for the first frame of a scene and reused afterwards; the lists themselves are
@@ -524,9 +533,9 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     g.cell_hdrs = c->d_hdrs;
     g.cell_nrm = reinterpret_cast<const float *>(c->d_nrm);
     if (nonempty > 0) {  // d_nbatch holds the list of the non-empty cells, its length at [ncells]
-      hipLaunchKernelGGL(k_grid_fill, dim3((nonempty + 3) / 4), dim3(256), 0, bs, c->nt, g, c->d_nbatch, c->d_box, c->d_recs_unsorted, c->d_refs);
-      hipLaunchKernelGGL(k_grid_sort, dim3(nonempty), dim3(kSortThreads), 0, bs, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs, c->d_nrm);
-      hipLaunchKernelGGL(k_grid_bounds, dim3(nonempty), dim3(256), 0, bs, g, c->d_nbatch, c->d_hdrs);
+      KLAUNCH(c, k_grid_fill, dim3((nonempty + 3) / 4), dim3(256), bs, c->nt, g, c->d_nbatch, c->d_box, c->d_recs_unsorted, c->d_refs);
+      KLAUNCH(c, k_grid_sort, dim3(nonempty), dim3(kSortThreads), bs, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs, c->d_nrm);
+      KLAUNCH(c, k_grid_bounds, dim3(nonempty), dim3(256), bs, g, c->d_nbatch, c->d_hdrs);
     }
   }
   if (piped) {
@@ -558,6 +567,19 @@ int rtgpu_grid_info_get(const rtgpu_ctx *c, rtgpu_grid_info *out) {
   return RTGPU_OK;
 }
 
+int64_t rtgpu_chunk_tile_limit(int fan, int levels, int nslots) {
+  if (fan < 0 || fan > 2 || levels < 1 || levels > kMaxLevels || nslots < 0) return -1;
+  // the deepest level holds tiles * 64 * fan^(levels-1) nodes; node indices are int32, and the shadow walk's items,
+  // nodes * nslots, are numbered by 32-bit tickets of 64 (Tickets::take): both must stay below 2^31 resp. 2^32 - 64
+  int64_t deepest = kTilePixels, all = kTilePixels;
+  for (int L = 1; L < levels; L++) { deepest *= fan; all += deepest; }
+  int64_t by_nodes = 0x7fffffffll / all;
+  const int64_t per_tile_items = (deepest > kTilePixels ? deepest : (int64_t)kTilePixels) * (nslots > 0 ? nslots : 1);
+  int64_t by_items = (0xffffffffll - 64) / per_tile_items;
+  const int64_t lim = by_nodes < by_items ? by_nodes : by_items;
+  return lim < 1 ? 1 : lim;
+}
+
 int64_t rtgpu_tile_count(const rtgpu_ctx *c, int rank, int world) {
   if (!c || !c->have_frame || world <= 0 || rank < 0 || rank >= world) return -1;
   return tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
@@ -576,21 +598,21 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   queued.on = 0;
   {
     Span sp(c, W_PRIMARY);  // the control block; the primary rays themselves are computed where they are used
-    hipLaunchKernelGGL(k_chunk_init, dim3(1), dim3(256), 0, c->stream, n0, c->d_ctl);
+    KLAUNCH(c, k_chunk_init, dim3(1), dim3(256), c->stream, n0, c->d_ctl);
   }
   for (int L = 0; L < c->levels; L++) {
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
     {
       Span sp(c, W_NEAREST);
       if (c->opt_count)
-        hipLaunchKernelGGL(k_nearest<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
+        KLAUNCH(c, k_nearest<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
       else
-        hipLaunchKernelGGL(k_nearest<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
+        KLAUNCH(c, k_nearest<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
     }
     {
       Span sp(c, W_HIT);
       const bool spawn = L + 1 < c->levels;
-      hipLaunchKernelGGL(k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
+      KLAUNCH(c, k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
                          c->d_nodes, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
                          spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn, L == 0 ? c->prim : queued);
     }
@@ -598,7 +620,7 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   if (c->npl > 0) {
     for (int L = c->levels - 1; L >= 0; L--) {
       const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-      hipLaunchKernelGGL(k_subtree_hits, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_ctl, L, (int)c->base[L]);
+      KLAUNCH(c, k_subtree_hits, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->d_nodes, c->d_size, c->d_ctl, L, (int)c->base[L]);
     }
   }
   return RTGPU_OK;
@@ -608,11 +630,11 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
 // sizes: the level-0 subtree sizes of every rank (per_rank entries each), or this rank's own for world = 1;
 // total_hits: shaded hits of the whole frame if known, else -1 (world = 1: read back from the device).
 int chunk_ranks(rtgpu_ctx *c, int n0, const int32_t *sizes, int64_t per_rank, int rank, int world, int64_t total_hits) {
-  hipLaunchKernelGGL(k_tree_starts, dim3(1), dim3(1024), 0, c->stream, c->cam.sw, c->cam.sh, (int)tiles_x_of(c), sizes, (long long)per_rank,
+  KLAUNCH(c, k_tree_starts, dim3(1), dim3(1024), c->stream, c->cam.sw, c->cam.sh, (int)tiles_x_of(c), sizes, (long long)per_rank,
                      world, rank, c->d_rank);
   for (int L = 0; L < c->levels; L++) {
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-    hipLaunchKernelGGL(k_assign_ranks, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->d_nodes, c->d_size, c->d_rank, c->d_ctl, L, (int)c->base[L]);
+    KLAUNCH(c, k_assign_ranks, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->d_nodes, c->d_size, c->d_rank, c->d_ctl, L, (int)c->base[L]);
   }
   if (c->fan > 0) {
     // secondary hits draw random numbers too: the table must cover every shaded hit of the frame (a host sync,
@@ -637,9 +659,9 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       Span sp(c, W_SHADOW);
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       if (c->opt_count)
-        hipLaunchKernelGGL(k_shadow<true>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+        KLAUNCH(c, k_shadow<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
       else
-        hipLaunchKernelGGL(k_shadow<false>, dim3(pgrid), dim3(256), 0, c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+        KLAUNCH(c, k_shadow<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
     }
   }
   PrimaryP queued = c->prim;
@@ -647,14 +669,14 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   for (int L = c->levels - 1; L >= 0; L--) {
     Span sp(c, W_ACCUM);
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), 0, c->stream, c->shade, c->d_rays[L], c->d_nodes,
+    KLAUNCH(c, k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->shade, c->d_rays[L], c->d_nodes,
                        c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
                        L == 0 ? c->d_partial : nullptr,  // level 0 (the last one) also folds the colour range of its blocks
                        L == 0 ? c->prim : queued);
   }
   {
     Span sp(c, W_MINMAX);
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(1024), 0, c->stream, c->d_partial, (n0 + 255) / 256, d_minmax,
+    KLAUNCH(c, k_minmax_final, dim3(1), dim3(1024), c->stream, c->d_partial, (n0 + 255) / 256, d_minmax,
                        (const Ctl *)c->d_ctl, c->d_totals);  // also the chunk's statistics into the frame totals
   }
   return RTGPU_OK;
@@ -668,7 +690,10 @@ int plan_chunks(rtgpu_ctx *c, int64_t ntiles, bool whole, int64_t *chunk_out) {
   if (chunk > ntiles) chunk = ntiles;
   if (whole && chunk < ntiles)
     return fail(c, RTGPU_E_UNSUPPORTED, "planar lights need this rank's whole share of the image in one chunk; raise chunk_bytes");
-  if ((int64_t)chunk * kTilePixels * (c->fan > 1 ? 16 : 1) > 0x7fffffffll) chunk = 0x7fffffffll / (kTilePixels * (c->fan > 1 ? 16 : 1));
+  const int64_t limit = rtgpu_chunk_tile_limit(c->fan, c->levels, c->shade.nslots);
+  if (whole && limit < ntiles)
+    return fail(c, RTGPU_E_UNSUPPORTED, "planar lights need this rank's whole share of the image in one chunk, and it has more items than the queues index");
+  if (chunk > limit) chunk = limit;
   *chunk_out = chunk;
   return ensure_chunk(c, (size_t)chunk);
 }
@@ -682,7 +707,7 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
     return fail(c, RTGPU_E_UNSUPPORTED, "planar lights on several GPUs: rtgpu_render_trace, exchange of rtgpu_hit_counts, rtgpu_render_shade");
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t ntiles = tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
-  hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, d_minmax, c->d_totals);
+  KLAUNCH(c, k_frame_init, dim3(1), dim3(64), c->stream, d_minmax, c->d_totals);
   c->split_tiles = -1;
   if (ntiles == 0) return RTGPU_OK;
   int64_t chunk = 0;
@@ -705,7 +730,7 @@ int rtgpu_render_trace(rtgpu_ctx *c, int rank, int world) {
   if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t ntiles = tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
-  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 32, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * kTotals, c->stream));
   c->split_tiles = -1;
   if (ntiles == 0) { c->split_tiles = 0; c->split_rank = rank; c->split_world = world; return RTGPU_OK; }
   int64_t chunk = 0;
@@ -735,7 +760,7 @@ int rtgpu_render_shade(rtgpu_ctx *c, const int32_t *d_all_counts, int64_t per_ra
   if (!c || !d_rgb || !d_ids || !d_minmax) return RTGPU_E_INVALID_PARAM;
   if (c->split_tiles < 0) return fail(c, RTGPU_E_STATE, "rtgpu_render_trace has not been called for this frame");
   HIPCHK(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, d_minmax);
+  KLAUNCH(c, k_minmax_init, dim3(1), dim3(64), c->stream, d_minmax);
   const int64_t ntiles = c->split_tiles;
   c->split_tiles = -1;
   if (ntiles == 0) return RTGPU_OK;
@@ -757,7 +782,7 @@ int rtgpu_tonemap(rtgpu_ctx *c, const float *d_rgb, int64_t n, const float *d_mi
   if (!c || !d_rgb || !d_minmax || !d_rgba || n < 0) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));
   if (n == 0) return RTGPU_OK;
-  hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_rgb, (long long)n, d_minmax, gamma, d_rgba);
+  KLAUNCH(c, k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), c->stream, d_rgb, (long long)n, d_minmax, gamma, d_rgba);
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
 }
@@ -767,7 +792,7 @@ int rtgpu_untile(rtgpu_ctx *c, const void *d_gathered, int world, int elem_bytes
   if (!c->have_frame) return RTGPU_E_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   const long long n = (long long)c->cam.sw * c->cam.sh, tx = tiles_x_of(c), ntiles = tx * tiles_y_of(c);
-  hipLaunchKernelGGL(k_untile, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t *)d_gathered, world, c->cam.sw,
+  KLAUNCH(c, k_untile, dim3((unsigned)((n + 255) / 256)), dim3(256), c->stream, (const uint32_t *)d_gathered, world, c->cam.sw,
                      c->cam.sh, (int)tx, ntiles, elem_bytes / 4, (uint32_t *)d_image);
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
@@ -784,7 +809,7 @@ int rtgpu_bmp_rows(rtgpu_ctx *c, const uint32_t *d_image, int32_t bpp, void *d_r
   HIPCHK(c, hipSetDevice(c->device));
   const int w = c->cam.sw, h = c->cam.sh, words = (int)(rtgpu_bmp_row_bytes(w, bpp) / 4);
   const long long n = (long long)words * h;
-  hipLaunchKernelGGL(k_bmp_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_image, w, h, bpp / 8, words, (uint32_t *)d_rows);
+  KLAUNCH(c, k_bmp_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), c->stream, d_image, w, h, bpp / 8, words, (uint32_t *)d_rows);
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
 }
@@ -812,7 +837,7 @@ int rtgpu_sync(rtgpu_ctx *c) {
 int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   if (!c || !out) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));
-  unsigned long long h[32];
+  unsigned long long h[kTotals];
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(h, c->d_totals, sizeof h, hipMemcpyDeviceToHost));
   memset(out, 0, sizeof *out);
@@ -832,7 +857,7 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   out->nearest_visits = (int64_t)h[kNearVisits]; out->shadow_visits = (int64_t)h[kShadVisits];
   out->nearest_batches = (int64_t)h[kNearBatches]; out->nearest_batches_culled = (int64_t)h[kNearCulled];
   out->shadow_batches = (int64_t)h[kShadBatches]; out->shadow_batches_culled = (int64_t)h[kShadCulled];
-  static_assert(kStatCount + kMaxLevels <= 32, "the totals buffer holds 32 counters");
+  out->nearest_full_tests = (int64_t)h[kNearFull]; out->shadow_full_tests = (int64_t)h[kShadFull];
   return RTGPU_OK;
 }
 

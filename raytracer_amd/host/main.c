@@ -76,13 +76,26 @@ int main(int argc, char **argv) {
     }
     if (f) fclose(f);
   }
+  /* Success is decided on what the calls return: the GPU runtime and stdio below may leave a stray errno on a
+   * path that worked, and the host layer's own codes are small positive numbers too. */
+  int failed = 0;
+  errno = 0;
   RT_Bitmap *bmp = rtVisualizedSceneToBitmap(vs, F_HDR, NULL);
-  if (bmp) rtBitmapSave(bmp, opt['o'], 24);
+  if (!bmp) {
+    fprintf(stderr, "problem while creating result image: %d, %s\n", errno, rtGetErrorDesc());
+    failed = 1;
+  } else {
+    errno = 0;
+    rtBitmapSave(bmp, opt['o'], 24);
+    if (errno == E_IO || errno == E_MEMORY || errno == E_INVALID_BPP) {
+      fprintf(stderr, "problem while saving result image: %d, %s\n", errno, rtGetErrorDesc());
+      failed = 1;
+    }
+  }
   rtBitmapDestroy(&bmp);
   rtVisualizedSceneDestroy(&vs);
   rtCameraDestroy(&cam);
   rtSceneDestroy(&scene);
   rtHostShutdown();
-  if (errno > 0) { fprintf(stderr, "problem while creating result image: %d, %s\n", errno, rtGetErrorDesc()); return 1; }
-  return 0;
+  return failed;
 }

@@ -50,11 +50,14 @@ NATIVE = {  # native-resolution known answers (ids + BMP digests)
 # larger frames kept as id buffer + 8-bit image (the reference's own BMP pixels, top row first, R G B)
 LARGE = {
     "ulica_384x216": ("scenes/ulica/ulica", {}, (384, 216)),   # ~3.5 minutes of reference time
+    "ulica_768x432": ("scenes/ulica/ulica", {}, (768, 432)),   # ~13 minutes: 64 lights, depth 5, several chunks of tiles on the GPU
 }
 
 
-def large():
+def large(only=None):
     for name, (prefix, over, (w, h)) in LARGE.items():
+        if only and name not in only:
+            continue
         r = O.run_reference(os.path.join(ROOT, prefix), width=w, height=h, cwd=os.path.join(ROOT, "scenes"), want_bmp=True)
         bmp = r["bmp"]
         img = np.frombuffer(bmp[54:], np.uint8).reshape(h, (w * 3 + 3) // 4 * 4)[:, :w * 3][::-1].reshape(h, w, 3)[:, :, ::-1]
@@ -69,7 +72,7 @@ def main():
     if not O.have_reference():
         sys.exit("build oracle/_ref first: make -C oracle ref")
     if len(sys.argv) > 1 and sys.argv[1] == "large":
-        return large()
+        return large(sys.argv[2:])   # make_golden.py large [<case> ...]
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "only" else None   # make_golden.py only <case> ...
     for name, (prefix, over, (w, h), tex) in CASES.items():
         if only is not None and name not in only:

@@ -132,6 +132,7 @@ def test_planar_lights_refuse_more_than_one_rank_in_one_call(renderer):
     n = renderer.tile_count(0, 2) * 64
     rgb = torch.zeros(n * 3, device="cuda"); ids = torch.zeros(n, dtype=torch.int32, device="cuda")
     mm = torch.zeros(6, device="cuda")
+    torch.cuda.synchronize()  # the context enqueues on its own stream, which does not wait for torch's
     with pytest.raises(rt.RtgpuError) as e:
         renderer.render(rgb, ids, mm, 0, 2)
     assert e.value.code == 102
@@ -156,17 +157,19 @@ def test_planar_lights_on_several_ranks_draw_rand_in_the_reference_order(rendere
         for k, r in enumerate(ranks):
             r.upload(scene); r.frame_begin(); r.render_trace(k, world)
             c = torch.zeros(r.tile_count(k, world) * 64, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()  # the contexts enqueue on their own streams, which do not wait for torch's
             r.hit_counts(c); r.sync()
             counts.append(c)
         per_rank = D.tile_count(ntiles, 0, world) * 64
         every = torch.zeros(world * per_rank, dtype=torch.int32, device="cuda")
         for k, c in enumerate(counts):
             every[k * per_rank:k * per_rank + c.numel()] = c
-        total = int(every.sum().item())
+        total = int(every.sum().item())  # (.item() waits for torch's stream: `every` is complete)
         rgbs, idss, mms = [], [], []
         for k, r in enumerate(ranks):
             n = r.tile_count(k, world) * 64
             rgb = torch.zeros(n * 3, device="cuda"); ids = torch.zeros(n, dtype=torch.int32, device="cuda"); mm = torch.zeros(6, device="cuda")
+            torch.cuda.synchronize()
             r.render_shade(rgb, ids, mm, every, per_rank, total); r.sync()
             rgbs.append(rgb.cpu().numpy().reshape(-1, 3)); idss.append(ids.cpu().numpy()); mms.append(mm.cpu().numpy())
         rgb = D.untile_reference(np.concatenate(rgbs), world, w, h)

@@ -157,12 +157,14 @@ def test_multi_rank_tiling_reassembles_the_frame(renderer):
         rgb = torch.zeros(n * 3, dtype=torch.float32, device=dev)
         ids = torch.zeros(n, dtype=torch.int32, device=dev)
         mm = torch.zeros(6, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)  # the context enqueues on its own stream, which does not wait for torch's zero fill
         renderer.render(rgb, ids, mm, rank, world)
         renderer.sync()
         rgb_parts.append(rgb); id_parts.append(ids); mms.append(mm.cpu().numpy())
     rgb_all, ids_all = torch.cat(rgb_parts), torch.cat(id_parts)
     img = torch.zeros(h * w * 3, dtype=torch.float32, device=dev)
     idi = torch.zeros(h * w, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)  # torch.cat and the zero fills above are complete before the context reads and writes
     renderer.untile(rgb_all, world, 12, img)
     renderer.untile(ids_all, world, 4, idi)
     renderer.sync()

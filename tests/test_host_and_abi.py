@@ -158,3 +158,24 @@ def test_geometry_cache_gives_the_same_scene_and_notices_a_changed_source(tmp_pa
     fresh = rt.Scene(str(src))
     assert np.array_equal(third.vertices().view(np.uint32), fresh.vertices().view(np.uint32))
     assert not np.array_equal(third.vertices(), plain.vertices())
+
+
+def test_chunk_limit_keeps_items_inside_32_bit_tickets():
+    """The walk kernels number their work items with 32-bit tickets of 64 and nodes with int32: the chunk planner's
+    bound (needs no GPU) keeps tiles * 64 * fan^(levels-1) * nslots below 2^32 and the node count below 2^31."""
+    L = rt.gpu_lib()
+    L.rtgpu_chunk_tile_limit.restype = ctypes.c_int64
+    L.rtgpu_chunk_tile_limit.argtypes = [ctypes.c_int] * 3
+    for fan, levels, nslots in [(0, 1, 6), (0, 1, 26), (0, 1, 64), (1, 5, 6), (2, 5, 64), (2, 5, 80), (0, 1, 0), (2, 5, 100000)]:
+        lim = int(L.rtgpu_chunk_tile_limit(fan, levels, nslots))
+        assert lim >= 1
+        deepest = 64 * fan ** (levels - 1) if levels > 1 else 64
+        nodes = sum(64 * fan ** k for k in range(levels)) if levels > 1 else 64
+        items = lim * max(deepest, 64) * max(nslots, 1)
+        if lim > 1:
+            assert items + 64 <= 2 ** 32 - 1 and lim * nodes <= 2 ** 31 - 1
+            # and the bound is tight: one more tile would break one of the two
+            assert (lim + 1) * max(deepest, 64) * max(nslots, 1) + 64 > 2 ** 32 - 1 or (lim + 1) * nodes > 2 ** 31 - 1
+    # the case of the review: a scene without secondary rays, 26 lights, more than 67 M pixels in one chunk
+    assert int(L.rtgpu_chunk_tile_limit(0, 1, 26)) * 64 * 26 < 2 ** 32
+    assert int(L.rtgpu_chunk_tile_limit(3, 5, 6)) == -1 and int(L.rtgpu_chunk_tile_limit(1, 6, 6)) == -1

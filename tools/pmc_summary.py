@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc CSV output: per kernel, mean of each counter over its dispatches.
-usage: tools/pmc_summary.py gpurun_out/pmc_<tag>_*     (also writes profiles/pmc.json: the means, machine-readable)"""
+usage: tools/pmc_summary.py [--workload "temple 3840x2160"] gpurun_out/pmc_<tag>_*
+Also writes profiles/pmc.json: the means, machine-readable, stamped with the workload and with the SHA-256 of the
+kernel sources they were collected on (bench.py ignores the file when that differs from its own tree's)."""
 import csv
 import json
 import glob
@@ -8,8 +10,16 @@ import os
 import sys
 from collections import defaultdict
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd.api import csrc_hash  # noqa: E402
+
+argv = sys.argv[1:]
+workload = "temple 3840x2160"
+if argv and argv[0] == "--workload":
+    workload, argv = argv[1], argv[2:]
 acc = defaultdict(lambda: defaultdict(list))
-for d in sys.argv[1:]:
+for d in argv:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -22,11 +32,11 @@ for k in sorted(acc):
         v = acc[k][c]
         print("   %-28s %16.0f  (n=%d)" % (c, sum(v) / len(v), len(v)))
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 for k in acc:
     for fam in ("k_shadow<false>", "k_nearest<false>"):
         if fam in k:
             out[fam.split("<")[0]] = {c: sum(v) / len(v) for c, v in acc[k].items()}
 if out:
-    json.dump({"method": "rocprofv3 --pmc, means over the launches of one bench run", **out}, open(os.path.join(ROOT, "profiles", "pmc.json"), "w"), indent=1)
+    json.dump({"method": "rocprofv3 --pmc, means over the launches of one run of tools/kbench.py --one", "workload": workload,
+               "csrc_sha256": csrc_hash(), **out}, open(os.path.join(ROOT, "profiles", "pmc.json"), "w"), indent=1)

@@ -12,12 +12,14 @@ import sys
 from collections import defaultdict
 
 root, scene, w, h = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+sys.path.insert(0, os.path.dirname(os.path.abspath(root)))
+from raytracer_amd.api import csrc_hash  # noqa: E402
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "traffic_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("rt::", "").split("<")[0]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {"workload": "%s %sx%s" % (scene, w, h), "method": "rocprofv3 --pmc, one counter set per run; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+out = {"workload": "%s %sx%s" % (scene, w, h), "csrc_sha256": csrc_hash(), "method": "rocprofv3 --pmc, one counter set per run; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
 for k in ("k_nearest", "k_shadow", "k_hit", "k_accumulate"):
     if k not in acc:
         continue
@@ -25,6 +27,6 @@ for k in ("k_nearest", "k_shadow", "k_hit", "k_accumulate"):
     fetch, write = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
     hit, miss = m.get("TCC_HIT_sum", 0.0), m.get("TCC_MISS_sum", 0.0)
     out[k] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
-              "l2_hit_rate": hit / (hit + miss) if hit + miss else None, "launches_averaged": len(next(iter(acc[k].values())))}
+              "l2_hit_rate": hit / (hit + miss) if hit + miss else None, "l2_requests_per_launch": hit + miss, "launches_averaged": len(next(iter(acc[k].values())))}
 json.dump(out, open(os.path.join(os.path.dirname(root), "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
