@@ -28,6 +28,12 @@
 
 static rtgpu_ctx *g_ctx; /* one context per process and GPU, created at the first frame */
 
+/* The reference's main() tests errno before anything has set it (src/main.c:119-122) and stops with "unable to parse
+ * args" if it is positive.  The GPU runtime that librtgpu brings in initialises itself while the program is loaded and
+ * leaves ENOENT (= 2, the reference's E_MEMORY) behind; the program's own constructors run after those of its
+ * libraries, so this one restores the value main() expects. */
+__attribute__((constructor)) static void clear_load_time_errno(void) { errno = 0; }
+
 static rtgpu_ctx *context(void) {
   if (!g_ctx) {
     const char *dev = getenv("RTGPU_DEVICE");
