@@ -171,6 +171,20 @@ int64_t rtgpu_chunk_tile_limit(int fan, int levels, int nslots);
  * Asynchronous on the context's stream; rtgpu_sync waits. */
 int rtgpu_render(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax);
 
+/* No counterpart in the reference.  rtgpu_render for callers that cannot allocate device memory (code under HIP graph
+ * capture, serving loops, harnesses that forbid hipMalloc): same arguments, same outputs bit for bit, but the queues of
+ * the pixel loop (hits, shaded-hit nodes, secondary rays, shadow results, partial colour ranges) live in a static device
+ * array of rtgpu_static_scratch_bytes() = 64 MiB that every GPU the library runs on holds until the process ends; the
+ * call makes no hipMalloc, hipFree or other allocating call (per-kernel "timing" is off for it: it would create events).
+ * This rank's whole share of the image is traced as one chunk, so its queues have to fit the array (temple: 124 bytes per
+ * pixel, about 540 000 pixels; ulica, 64 lights and depth 5: about 11 KB per pixel); a larger share, a scene with planar
+ * lights (their random-number table is sized at run time) or a device index above 63 is refused with
+ * RTGPU_E_UNSUPPORTED and a message that says which, before anything is enqueued.  All contexts of one GPU share that
+ * GPU's array and it keeps the last call's contents (nothing in it has to be cleared: every entry is written before
+ * it is read): calls that overlap on one GPU, from two contexts or two streams, race; calls on one stream do not. */
+int rtgpu_render_static(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax);
+int64_t rtgpu_static_scratch_bytes(void);
+
 /* rtgpu_render in two halves, for planar lights on several GPUs.  The reference draws rand() per shaded hit in
  * pixel order (src/raytrace.c:241-262, each pixel's ray tree in post-order), so a rank has to know how many shaded
  * hits the pixels before its own have, on whichever rank they are:

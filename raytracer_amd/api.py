@@ -134,6 +134,11 @@ def gpu_lib():
         L.rtgpu_tile_count.restype = i64
         L.rtgpu_tile_count.argtypes = [vp, i32, i32]
         L.rtgpu_render.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.rtgpu_render_static.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.rtgpu_static_scratch_bytes.restype = i64
+        L.rtgpu_static_scratch_bytes.argtypes = []
+        L.rtgpu_chunk_tile_limit.restype = i64
+        L.rtgpu_chunk_tile_limit.argtypes = [i32, i32, i32]
         L.rtgpu_render_trace.argtypes = [vp, i32, i32]
         L.rtgpu_hit_counts.argtypes = [vp, vp]
         L.rtgpu_render_shade.argtypes = [vp, vp, i64, i64, vp, vp, vp]
@@ -345,6 +350,10 @@ class Renderer:
     def render(self, rgb, ids, minmax, rank=0, world=1):
         """rgb/ids/minmax: device buffers (torch CUDA tensors or raw pointers), tile-major."""
         self._chk(self._L.rtgpu_render(self._h, rank, world, _ptr(rgb), _ptr(ids), _ptr(minmax)), "rtgpu_render")
+
+    def render_static(self, rgb, ids, minmax, rank=0, world=1):
+        """render() with the queues in the library's static scratch array: no device memory is allocated."""
+        self._chk(self._L.rtgpu_render_static(self._h, rank, world, _ptr(rgb), _ptr(ids), _ptr(minmax)), "rtgpu_render_static")
 
     def render_trace(self, rank=0, world=1):
         """First half of render(): everything up to the hits (see rtgpu_render_trace)."""

@@ -18,6 +18,16 @@
 
 using namespace rt;
 
+// Device memory of rtgpu_render_static, the entry point that allocates nothing: the queues of one chunk live in this
+// array instead of memory from hipMalloc.  Every GPU the library runs on holds its own copy, at its own address, until
+// the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress (rtgpu_create asks once
+// per device, with that device current, and keeps the answer in g_scratch_ptr); everything that needs the memory
+// (kernel arguments) takes that per-device pointer.
+constexpr size_t kScratchBytes = 64ull << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];  // device address of `scratch` on every device a context was created on
+
 namespace {
 
 struct TimedSpan { hipEvent_t a, b; int what; };
@@ -95,6 +105,7 @@ struct rtgpu_ctx {
   PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
   int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
   Ctl *d_ctl = nullptr;
+  unsigned char *scratch = nullptr;  // this device's copy of the static scratch array (rtgpu_render_static)
   unsigned long long *d_totals = nullptr;  // [kStatCount + kMaxLevels + 1]
   // timing
   std::vector<TimedSpan> spans;
@@ -207,9 +218,11 @@ int64_t tiles_x_of(const rtgpu_ctx *c) { return (c->cam.sw + kTile - 1) / kTile;
 int64_t tiles_y_of(const rtgpu_ctx *c) { return (c->cam.sh + kTile - 1) / kTile; }
 int64_t tiles_of_rank(int64_t ntiles, int rank, int world) { return rank < ntiles ? (ntiles - rank + world - 1) / world : 0; }
 
-// Queues of one chunk: level L holds at most cap[L] rays/nodes; a node has at most `fan` children.
-int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
-  if (tiles <= c->chunk_tiles_cap) return RTGPU_OK;
+// Queues of one chunk: level L holds at most cap[L] rays/nodes; a node has at most `fan` children.  plan_queues
+// sets the capacities for `tiles` tiles and asks give(slot, bytes) for the memory of every queue: ensure_chunk
+// allocates it, rtgpu_render_static carves it from the library's static scratch array.
+template <typename F>
+int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
   size_t total = 0, maxcap = 0;
   for (int L = 0; L < c->levels; L++) {
     c->cap[L] = L == 0 ? tiles * kTilePixels : c->cap[L - 1] * (size_t)c->fan;
@@ -220,16 +233,49 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
   c->total_nodes = total;
   int rc;
   for (int L = 0; L < c->levels; L++)
-    if ((rc = dev_alloc(c, &c->d_rays[L], L == 0 ? (size_t)1 : c->cap[L]))) return rc;  // (level 0: primary rays are not stored)
-  if ((rc = dev_alloc(c, &c->d_hits, maxcap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_nodes, total))) return rc;
-  if ((rc = dev_alloc(c, &c->d_colors, total * 4))) return rc;
-  if ((rc = dev_alloc(c, &c->d_ts, total * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)))) return rc;
-  if ((rc = dev_alloc(c, &c->d_partial, (tiles * kTilePixels + 255) / 256 * 6))) return rc;  // colour range per block of level 0
+    if ((rc = give((void **)&c->d_rays[L], sizeof(Ray) * (L == 0 ? (size_t)1 : c->cap[L])))) return rc;  // (level 0: primary rays are not stored)
+  if ((rc = give((void **)&c->d_hits, sizeof(Hit) * maxcap))) return rc;
+  if ((rc = give((void **)&c->d_nodes, sizeof(Node) * total))) return rc;
+  if ((rc = give((void **)&c->d_colors, sizeof(float) * total * 4))) return rc;
+  if ((rc = give((void **)&c->d_ts, sizeof(float) * total * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)))) return rc;
+  if ((rc = give((void **)&c->d_partial, sizeof(float) * ((tiles * kTilePixels + 255) / 256 * 6)))) return rc;  // colour range per block of level 0
   const size_t nrank = c->npl > 0 ? total : 1;
-  if ((rc = dev_alloc(c, &c->d_rank, nrank)) || (rc = dev_alloc(c, &c->d_size, nrank))) return rc;
+  if ((rc = give((void **)&c->d_rank, sizeof(int32_t) * nrank)) || (rc = give((void **)&c->d_size, sizeof(int32_t) * nrank))) return rc;
+  return RTGPU_OK;
+}
+
+int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
+  if (tiles <= c->chunk_tiles_cap) return RTGPU_OK;
+  c->chunk_tiles_cap = 0;
+  int rc = plan_queues(c, tiles, [&](void **slot, size_t bytes) {
+    if (*slot) { (void)hipFree(*slot); *slot = nullptr; }
+    HIPCHK(c, hipMalloc(slot, bytes ? bytes : 1));
+    return (int)RTGPU_OK;
+  });
+  if (rc) return rc;
   c->chunk_tiles_cap = tiles;
   return RTGPU_OK;
+}
+
+// The chunk queues of a context, as a value: rtgpu_render_static puts the carved ones in and the context's own back.
+struct QueueSet {
+  size_t chunk_tiles_cap, cap[kMaxLevels], base[kMaxLevels], total_nodes;
+  Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size;
+};
+QueueSet take_queues(rtgpu_ctx *c) {
+  QueueSet q;
+  q.chunk_tiles_cap = c->chunk_tiles_cap; q.total_nodes = c->total_nodes;
+  for (int L = 0; L < kMaxLevels; L++) { q.cap[L] = c->cap[L]; q.base[L] = c->base[L]; q.d_rays[L] = c->d_rays[L]; c->d_rays[L] = nullptr; }
+  q.d_hits = c->d_hits; q.d_nodes = c->d_nodes; q.d_colors = c->d_colors; q.d_ts = c->d_ts; q.d_partial = c->d_partial;
+  q.d_rank = c->d_rank; q.d_size = c->d_size;
+  c->d_hits = nullptr; c->d_nodes = nullptr; c->d_colors = c->d_ts = c->d_partial = nullptr; c->d_rank = c->d_size = nullptr;
+  return q;
+}
+void put_queues(rtgpu_ctx *c, const QueueSet &q) {
+  c->chunk_tiles_cap = q.chunk_tiles_cap; c->total_nodes = q.total_nodes;
+  for (int L = 0; L < kMaxLevels; L++) { c->cap[L] = q.cap[L]; c->base[L] = q.base[L]; c->d_rays[L] = q.d_rays[L]; }
+  c->d_hits = q.d_hits; c->d_nodes = q.d_nodes; c->d_colors = q.d_colors; c->d_ts = q.d_ts; c->d_partial = q.d_partial;
+  c->d_rank = q.d_rank; c->d_size = q.d_size;
 }
 
 // The glibc rand() stream from seed 1, at least `need` values, on the device.
@@ -294,6 +340,15 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
       hipEventCreateWithFlags(&c->ev_released[1], hipEventDisableTiming) != hipSuccess) {
     rtgpu_destroy(c);
     return RTGPU_E_NO_DEVICE;
+  }
+  // this device's address of the static scratch array, asked once per device while that device is current
+  if (device < kMaxDevices) {
+    if (!g_scratch_ptr[device]) {
+      void *p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) { rtgpu_destroy(c); return RTGPU_E_NO_DEVICE; }
+      g_scratch_ptr[device] = p;
+    }
+    c->scratch = static_cast<unsigned char *>(g_scratch_ptr[device]);
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
@@ -721,6 +776,56 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
     if ((rc = chunk_shade(c, t0, nt_chunk, d_rgb, d_ids, d_minmax))) return rc;
   }
   mark_released(c);
+  HIPCHK(c, hipGetLastError());
+  return RTGPU_OK;
+}
+
+int64_t rtgpu_static_scratch_bytes(void) { return (int64_t)kScratchBytes; }
+
+int rtgpu_render_static(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax) {
+  if (!c || !d_rgb || !d_ids || !d_minmax || world <= 0 || rank < 0 || rank >= world) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
+  if (!c->scratch) return fail(c, RTGPU_E_UNSUPPORTED, "rtgpu_render_static: no static scratch array on this device index");
+  if (c->npl > 0)
+    return fail(c, RTGPU_E_UNSUPPORTED, "rtgpu_render_static: planar lights need a table of random numbers sized at run time; use rtgpu_render");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t ntiles = tiles_of_rank(tiles_x_of(c) * tiles_y_of(c), rank, world);
+  // the whole share is one chunk, and its queues must fit the array: sizes first, nothing is touched on refusal
+  if (ntiles > rtgpu_chunk_tile_limit(c->fan, c->levels, c->shade.nslots))
+    return fail(c, RTGPU_E_UNSUPPORTED, "rtgpu_render_static: this rank's share has more work items than one chunk can number; use rtgpu_render");
+  const QueueSet own = take_queues(c);
+  size_t need = 0;
+  (void)plan_queues(c, (size_t)ntiles, [&](void **, size_t bytes) { need += (bytes + 255) & ~(size_t)255; return (int)RTGPU_OK; });
+  if (need > kScratchBytes) {
+    put_queues(c, own);
+    return fail(c, RTGPU_E_UNSUPPORTED, "rtgpu_render_static: the queues of this rank's share need " + std::to_string(need) +
+                                            " bytes, the static scratch array holds " + std::to_string(kScratchBytes) +
+                                            "; render fewer tiles per rank or use rtgpu_render");
+  }
+  size_t off = 0;
+  (void)plan_queues(c, (size_t)ntiles, [&](void **slot, size_t bytes) {
+    *slot = c->scratch + off;
+    off += (bytes + 255) & ~(size_t)255;
+    return (int)RTGPU_OK;
+  });
+  // Nothing in the array has to start at zero: every queue entry is written by the kernel that produces it before the
+  // kernel that consumes it reads it (hits, nodes, ts and colours of shaded hits, one partial range per block of
+  // level 0), and the counters live in the context's control block, which k_chunk_init resets.
+  const bool timing = c->opt_timing;
+  c->opt_timing = false;  // (the per-kernel timing creates events: an allocating call)
+  c->split_tiles = -1;
+  int rc = RTGPU_OK;
+  do {
+    hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, d_minmax, c->d_totals);
+    if (ntiles == 0) break;
+    c->grid.slack = c->filter ? 0.0f : INFINITY;
+    if ((rc = chunk_trace(c, 0, (int)ntiles, rank, world))) break;
+    if ((rc = chunk_shade(c, 0, (int)ntiles, d_rgb, d_ids, d_minmax))) break;
+    mark_released(c);
+  } while (0);
+  c->opt_timing = timing;
+  put_queues(c, own);
+  if (rc) return rc;
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
 }
