@@ -11,7 +11,8 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-fast-ma
 CFLAGS   := -O2 -std=gnu99 -ffp-contract=off -fPIC -Wall
 HOSTSRC  := $(PKG)/host/scene.c $(PKG)/host/bitmap.c $(PKG)/host/raytrace.c $(PKG)/host/error.c
 
-all: $(PKG)/librtgpu.so $(PKG)/librthost.so $(PKG)/raytrace
+ROCM    ?= /opt/rocm
+all: $(PKG)/librtgpu.so $(PKG)/librthost.so $(PKG)/librtmulti.so $(PKG)/raytrace
 
 $(PKG)/librtgpu.so: $(PKG)/csrc/rtgpu.hip $(wildcard $(PKG)/csrc/*.h) include/rtgpu.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
@@ -19,14 +20,18 @@ $(PKG)/librtgpu.so: $(PKG)/csrc/rtgpu.hip $(wildcard $(PKG)/csrc/*.h) include/rt
 $(PKG)/librthost.so: $(HOSTSRC) $(PKG)/host/rt_host.h include/rtgpu.h $(PKG)/librtgpu.so
 	$(CC) $(CFLAGS) -shared -o $@ $(HOSTSRC) -L$(PKG) -lrtgpu -Wl,-rpath,'$$ORIGIN' -lm
 
+# the N-GPU host (one process, RCCL): its own library, loaded by the command line only for --devices
+$(PKG)/librtmulti.so: $(PKG)/host/multigpu.c $(PKG)/host/rt_host.h include/rtgpu.h $(PKG)/librthost.so
+	$(CC) $(CFLAGS) -I$(ROCM)/include -shared -o $@ $< -L$(PKG) -lrthost -lrtgpu -L$(ROCM)/lib -lrccl -lamdhip64 -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib -lm
+
 $(PKG)/raytrace: $(PKG)/host/main.c $(PKG)/librthost.so
-	$(CC) $(CFLAGS) -o $@ $< -L$(PKG) -lrthost -lrtgpu -Wl,-rpath,'$$ORIGIN' -lm
+	$(CC) $(CFLAGS) -o $@ $< -L$(PKG) -lrthost -lrtgpu -Wl,-rpath,'$$ORIGIN' -lm -ldl
 
 oracle:
 	$(MAKE) -C oracle oracle
 	if [ -d /root/reference/src ]; then $(MAKE) -C oracle ref dropin; fi
 
 clean:
-	rm -f $(PKG)/librtgpu.so $(PKG)/librthost.so $(PKG)/raytrace
+	rm -f $(PKG)/librtgpu.so $(PKG)/librthost.so $(PKG)/librtmulti.so $(PKG)/raytrace
 
 .PHONY: all oracle clean

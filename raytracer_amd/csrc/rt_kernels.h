@@ -240,6 +240,9 @@ RT_D bool box_test_ray(f3 c, float delta_and_flag, f3 hw, float W, f3 r, f3 m, f
 // batch_cos, 3 batch culling, 4 record staging, 5 triangle tests (3 and 4 are counted in 5 unless RT_PHASES=2),
 // 6 stepping to the next occupied cell, 7 lane and ray mode.
 __device__ unsigned long long g_phase[16];
+#ifdef RT_HIST
+__device__ unsigned long long g_hist[2][2][9];  // [walk][0 = batches, 1 = (lane, record) pairs][records of the batch some lane passed]
+#endif
 // Per-ticket log of the walk kernels, only in builds with -DRT_TICKETS (tools/tickets.py): shader clocks from
 // taking the ticket to its last result, cell visits, batches that reached the ray-by-ray test, records tested.
 #ifdef RT_TICKETS
@@ -403,6 +406,13 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       const v2f k = *reinterpret_cast<const v2f *>(hs + b * kHdrFloats + 8);  // k1, -+k2
       batch(k.x, __builtin_fabsf(k.y));
       tally(-2, n);  // n records are about to be tested
+#ifdef RT_HIST
+      {
+        int hrec = 0, hpairs = 0;
+        for (int q = 0; q < n; q++) { const unsigned long long mm = __ballot(pass1(rb + q * kRecFloats)); hrec += mm != 0; hpairs += __popcll(mm); }
+        if (lane == 0) { atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][0][hrec], 1ull); atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][1][hrec], (unsigned long long)hpairs); }
+      }
+#endif
       int j = 0;
       for (; j + RT_UNROLL <= n; j += RT_UNROLL) {
         unsigned long long m[RT_UNROLL], any = 0;
@@ -1233,7 +1243,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
 // refracted rays.  Children are appended to the next level's queue with one atomic per wavefront
 // (ballot + prefix count), so a child's slot is its parent's link.
 __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__restrict__ rays, const Hit *__restrict__ hits,
-                                             Node *__restrict__ nodes, const float *__restrict__ geom,
+                                             Node *__restrict__ nodes, SOrigin *__restrict__ sorg, const float *__restrict__ geom,
                                              Ray *__restrict__ next_rays, Ctl *__restrict__ ctl, int level,
                                              int node_base, int next_base, int next_cap, bool spawn, PrimaryP prim) {
   const int n = ctl->count[level];
@@ -1291,7 +1301,12 @@ __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__re
       }
     }
   }
-  if (valid) nodes[node_base + idx] = nd;
+  if (valid) {
+    nodes[node_base + idx] = nd;
+    SOrigin so;
+    so.p[0] = nd.p[0]; so.p[1] = nd.p[1]; so.p[2] = nd.p[2]; so.tri = nd.tri;
+    sorg[node_base + idx] = so;
+  }
 }
 
 // Replay of the order in which the reference consumes rand() for planar lights (raytrace.c:245-251).
@@ -1386,13 +1401,14 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 // ------------------------------------------------------------------------------------------------
 // Shadow walk (voxelize.c:615-738), any-hit, persistent wavefront kernel with the same per-cell
 // organisation as k_nearest.  Work item = (shadow slot, shaded hit) in slot-major order, so the 64
-// lanes of a batch are neighbouring hit points looking at the same light.  Result per item: the
-// transparency product ts (>= 0) if the light is visible, -1 if the point is in shadow.
+// lanes of a ticket are neighbouring hit points looking at the same light.  Result per item: the
+// transparency product ts (>= 0) if the light is visible, -1 if the point is in shadow, stored slot-major too
+// (ts_out[slot * ts_stride + node]: one full line per ticket).
 // The reference's per-triangle shadow cache (voxelize.c:647-655) is scan-order state; it is dropped.
 template <bool COUNT>
-__global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const Node *__restrict__ nodes,
+__global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const SOrigin *__restrict__ sorg,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
-                                                Ctl *__restrict__ ctl, int level, int node_base) {
+                                                long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
@@ -1430,7 +1446,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         slot = (int)(slot0 + rest / (uint32_t)n);
         nidx = (int)(rest % (uint32_t)n);
       }
-      const Node nd = nodes[node_base + nidx];
+      const SOrigin nd = sorg[node_base + nidx];
       current = nd.tri;
       if (current >= 0) {
         if (COUNT) nQ++;
@@ -1587,7 +1603,8 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       }
       ph.end<6>();
     }
-    if (have_result) ts_out[(long long)(node_base + nidx) * sp.nslots + slot] = result < 0.0f ? -1.0f : ts;
+    // slot-major: the 64 lanes of a ticket are consecutive hits of one slot, so the store is one 256-byte line
+    if (have_result) ts_out[(long long)slot * ts_stride + (node_base + nidx)] = result < 0.0f ? -1.0f : ts;
     RT_TICKET(ph.end<0>(); if (level == 0) tl.end(1, base, lane, ph); busy += __builtin_amdgcn_s_memtime() - tl.t0;)
   }
   RT_TICKET(if (level == 0) TicketLog::life(1, lane, busy, born);)
@@ -1639,7 +1656,7 @@ RT_D f3 light_term(const SurfaceD &sf, f3 norm, f3 r, f3 rnew, f3 onew, f3 lpos,
 // (16 samples each, accumulated exactly as written, quirks included).  Levels run deepest first so a
 // node finds its children's colours ready.  Level 0 also writes the tile-major framebuffer.
 __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__restrict__ rays, const Node *__restrict__ nodes,
-                                                    const float *__restrict__ ts_in, const int32_t *__restrict__ rand_rank,
+                                                    const float *__restrict__ ts_in, long long ts_stride, const int32_t *__restrict__ rand_rank,
                                                     float *__restrict__ colors, Ctl *__restrict__ ctl, int level,
                                                     int node_base, float *__restrict__ fb_rgb, int32_t *__restrict__ fb_ids,
                                                     long long fb_base, float *__restrict__ partial, PrimaryP prim) {
@@ -1665,10 +1682,10 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
       f3 rc = nd.refr >= 0 ? ld3(colors + 4ll * nd.refr) : mk3(0.0f, 0.0f, 0.0f);
       res = add3(res, mul3(rc, sf.kt));
     }
-    const float *ts = ts_in + (long long)gidx * sp.nslots;
+    const float *ts = ts_in + gidx;  // slot s of this node: ts[s * ts_stride]
     f3 tmp = mk3(0.0f, 0.0f, 0.0f);
     for (int c = 0; c < sp.nl; c++) {
-      const float t = ts[c];
+      const float t = ts[c * ts_stride];
       if (t >= 0.0f) {
         const LightD L = sp.lights[c];
         const f3 lp = ld3(L.p);
@@ -1680,7 +1697,7 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
       f3 sum = mk3(0.0f, 0.0f, 0.0f);
       for (int d = 0; d < kPlanarSamples; d++) {
         const int slot = sp.nl + c * kPlanarSamples + d;
-        const float t = ts[slot];
+        const float t = ts[slot * ts_stride];
         if (t >= 0.0f) {
           f3 lp, lcol; float lflux;
           slot_light(sp, slot, rand_rank[gidx], lp, lflux, lcol);

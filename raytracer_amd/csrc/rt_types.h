@@ -108,6 +108,14 @@ struct __attribute__((aligned(16))) Node {
 };
 static_assert(sizeof(Node) == 48, "Node is 48 bytes");
 
+// What a shadow query needs of a shaded hit (src/voxelize.c:615-644): the hit point and the triangle it lies on
+// (>= 0 triangle, -1 miss, -2 no ray).  The shadow walk reads one of these per (hit, light) instead of the 48-byte node.
+struct __attribute__((aligned(16))) SOrigin {
+  float p[3];
+  int32_t tri;
+};
+static_assert(sizeof(SOrigin) == 16, "SOrigin is 16 bytes");
+
 struct SurfaceD { float color[3]; float kd, ks, g, ka, kt, eta, kr; };
 struct LightD { float p[3]; float flux; float color[3]; };
 struct PlanarD { float flux; float color[3]; float a[3], ab[3], ac[3]; };

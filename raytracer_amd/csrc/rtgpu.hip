@@ -101,6 +101,7 @@ struct rtgpu_ctx {
   Ray *d_rays[kMaxLevels] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   Hit *d_hits = nullptr;  // sized for the largest level
   Node *d_nodes = nullptr;
+  SOrigin *d_sorg = nullptr;  // hit point + triangle of every node: what the shadow walk reads
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
   PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
   int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
@@ -236,6 +237,7 @@ int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
     if ((rc = give((void **)&c->d_rays[L], sizeof(Ray) * (L == 0 ? (size_t)1 : c->cap[L])))) return rc;  // (level 0: primary rays are not stored)
   if ((rc = give((void **)&c->d_hits, sizeof(Hit) * maxcap))) return rc;
   if ((rc = give((void **)&c->d_nodes, sizeof(Node) * total))) return rc;
+  if ((rc = give((void **)&c->d_sorg, sizeof(SOrigin) * total))) return rc;
   if ((rc = give((void **)&c->d_colors, sizeof(float) * total * 4))) return rc;
   if ((rc = give((void **)&c->d_ts, sizeof(float) * total * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)))) return rc;
   if ((rc = give((void **)&c->d_partial, sizeof(float) * ((tiles * kTilePixels + 255) / 256 * 6)))) return rc;  // colour range per block of level 0
@@ -260,21 +262,21 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
 // The chunk queues of a context, as a value: rtgpu_render_static puts the carved ones in and the context's own back.
 struct QueueSet {
   size_t chunk_tiles_cap, cap[kMaxLevels], base[kMaxLevels], total_nodes;
-  Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size;
+  Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; SOrigin *d_sorg; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size;
 };
 QueueSet take_queues(rtgpu_ctx *c) {
   QueueSet q;
   q.chunk_tiles_cap = c->chunk_tiles_cap; q.total_nodes = c->total_nodes;
   for (int L = 0; L < kMaxLevels; L++) { q.cap[L] = c->cap[L]; q.base[L] = c->base[L]; q.d_rays[L] = c->d_rays[L]; c->d_rays[L] = nullptr; }
-  q.d_hits = c->d_hits; q.d_nodes = c->d_nodes; q.d_colors = c->d_colors; q.d_ts = c->d_ts; q.d_partial = c->d_partial;
+  q.d_hits = c->d_hits; q.d_nodes = c->d_nodes; q.d_sorg = c->d_sorg; q.d_colors = c->d_colors; q.d_ts = c->d_ts; q.d_partial = c->d_partial;
   q.d_rank = c->d_rank; q.d_size = c->d_size;
-  c->d_hits = nullptr; c->d_nodes = nullptr; c->d_colors = c->d_ts = c->d_partial = nullptr; c->d_rank = c->d_size = nullptr;
+  c->d_hits = nullptr; c->d_nodes = nullptr; c->d_sorg = nullptr; c->d_colors = c->d_ts = c->d_partial = nullptr; c->d_rank = c->d_size = nullptr;
   return q;
 }
 void put_queues(rtgpu_ctx *c, const QueueSet &q) {
   c->chunk_tiles_cap = q.chunk_tiles_cap; c->total_nodes = q.total_nodes;
   for (int L = 0; L < kMaxLevels; L++) { c->cap[L] = q.cap[L]; c->base[L] = q.base[L]; c->d_rays[L] = q.d_rays[L]; }
-  c->d_hits = q.d_hits; c->d_nodes = q.d_nodes; c->d_colors = q.d_colors; c->d_ts = q.d_ts; c->d_partial = q.d_partial;
+  c->d_hits = q.d_hits; c->d_nodes = q.d_nodes; c->d_sorg = q.d_sorg; c->d_colors = q.d_colors; c->d_ts = q.d_ts; c->d_partial = q.d_partial;
   c->d_rank = q.d_rank; c->d_size = q.d_size;
 }
 
@@ -298,7 +300,7 @@ size_t bytes_per_tile(const rtgpu_ctx *c) {
     nodes += capL;
     maxcap = capL > maxcap ? capL : maxcap;
   }
-  return nodes * (sizeof(Ray) + sizeof(Node) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) -
+  return nodes * (sizeof(Ray) + sizeof(Node) + sizeof(SOrigin) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) -
          kTilePixels * sizeof(Ray) + maxcap * sizeof(Hit) + kTilePixels * 4;  // (no ray queue for level 0)
 }
 
@@ -380,7 +382,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs); dev_free(&c->d_recs_unsorted);
   dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
-  dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
+  dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_ctl); dev_free(&c->d_totals);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -668,7 +670,7 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
       Span sp(c, W_HIT);
       const bool spawn = L + 1 < c->levels;
       KLAUNCH(c, k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
-                         c->d_nodes, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
+                         c->d_nodes, c->d_sorg, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
                          spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn, L == 0 ? c->prim : queued);
     }
   }
@@ -714,9 +716,9 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       Span sp(c, W_SHADOW);
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       if (c->opt_count)
-        KLAUNCH(c, k_shadow<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+        KLAUNCH(c, k_shadow<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L]);
       else
-        KLAUNCH(c, k_shadow<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_nodes, rr, c->d_ts, c->d_ctl, L, (int)c->base[L]);
+        KLAUNCH(c, k_shadow<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L]);
     }
   }
   PrimaryP queued = c->prim;
@@ -725,7 +727,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
     Span sp(c, W_ACCUM);
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
     KLAUNCH(c, k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->shade, c->d_rays[L], c->d_nodes,
-                       c->d_ts, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
+                       c->d_ts, (long long)c->total_nodes, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
                        L == 0 ? c->d_partial : nullptr,  // level 0 (the last one) also folds the colour range of its blocks
                        L == 0 ? c->prim : queued);
   }
@@ -979,6 +981,15 @@ int rtgpu_phase_cycles(rtgpu_ctx *c, int64_t out[16], int reset) {
   }
   return RTGPU_OK;
 }
+
+#ifdef RT_HIST
+int rtgpu_debug_hist(rtgpu_ctx *c, unsigned long long *out) {
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(unsigned long long) * 36));
+  return RTGPU_OK;
+}
+#endif
 
 int rtgpu_ticket_log(rtgpu_ctx *c, int which, uint32_t *out, int max_tickets, int *copied) {
   if (!c || !out || !copied || which < 0 || which > 1) return RTGPU_E_INVALID_PARAM;

@@ -1,8 +1,14 @@
 /* Command line of the ray tracer: the reference's options (src/main.c:36-104) plus -W/-H to override
- * the camera resolution, -d to pick the GPU and -I to dump primary-hit triangle ids.
+ * the camera resolution, -d to pick the GPU, -I to dump primary-hit triangle ids and --devices N to split the
+ * frame by image tiles over N GPUs of this node (one process, RCCL: host/multigpu.c).
  */
+#define _GNU_SOURCE
 #include "rt_host.h"
 
+#include <dlfcn.h>
+#include <libgen.h>
+#include <limits.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -16,7 +22,9 @@ static void usage(const char *exe) {
          "    -G gamma   -E epsilon   -D distmod   (a .cfg file overrides them)\n"
          "    -W width -H height  override the camera resolution    -d N  GPU index\n"
          "    -I PATH  also write primary-hit triangle ids (int32, row-major, -1 = none)\n"
-         "    -B PATH  binary cache of the geometry file (written if missing or older than its source)\n", exe);
+         "    -B PATH  binary cache of the geometry file (written if missing or older than its source)\n"
+         "    --devices N  split the frame by 8x8 tiles over GPUs 0..N-1 (RCCL: colour range all-reduce, RGBA8 tile gather)\n"
+         "    --frames K   with --devices: render K frames and report the time per frame after the first\n", exe);
 }
 
 static char *join(const char *a, const char *b) {
@@ -30,10 +38,12 @@ int main(int argc, char **argv) {
   const char *letters = "glLacCsoGEDWHdIB";
   char *g, *l, *L, *a, *c, *C;
   float gamma = 2.5f, epsilon = 0.0f, distmod = 2.0f;
-  int i;
+  int i, devices = 0, frames = 1;
   if (argc <= 1) { usage(argv[0]); return 0; }
   for (i = 1; i < argc; i++) { /* value glued to the option ("-sPREFIX") or in the next argument */
     const char *arg = argv[i];
+    if (!strcmp(arg, "--devices") && i + 1 < argc) { devices = atoi(argv[++i]); if (devices < 1) { fprintf(stderr, "--devices needs a positive number\n"); return 1; } continue; }
+    if (!strcmp(arg, "--frames") && i + 1 < argc) { frames = atoi(argv[++i]); if (frames < 1) frames = 1; continue; }
     if (arg[0] != '-' || !arg[1] || !strchr(letters, arg[1])) { fprintf(stderr, "unknown option %s\n", arg); return 1; }
     if (arg[2]) opt[(int)arg[1]] = arg + 2;
     else if (i + 1 < argc) opt[(int)arg[1]] = argv[++i];
@@ -59,6 +69,31 @@ int main(int argc, char **argv) {
   RT_Camera *cam = rtCameraLoad(c);
   if (!cam || errno > 0) { fprintf(stderr, "unable to load camera: %s\n", rtGetErrorDesc()); return 1; }
   if (opt['W'] && opt['H']) { cam->sw = atoi(opt['W']); cam->sh = atoi(opt['H']); }
+
+  if (devices > 0) { /* one process, `devices` GPUs: librtmulti.so next to this program */
+    char exe[PATH_MAX], lib[PATH_MAX + 32];
+    ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+    RT_Bitmap *(*render)(RT_Scene *, RT_Camera *, int, int, double *);
+    void *h;
+    double secs = 0.0;
+    exe[n > 0 ? n : 0] = 0;
+    snprintf(lib, sizeof lib, "%s/librtmulti.so", dirname(exe));
+    h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { fprintf(stderr, "--devices: cannot load %s: %s\n", lib, dlerror()); return 1; }
+    *(void **)&render = dlsym(h, "rtHostRenderDevices");
+    if (!render) { fprintf(stderr, "--devices: %s\n", dlerror()); return 1; }
+    errno = 0;
+    RT_Bitmap *out = render(scene, cam, devices, frames, &secs);
+    if (!out) { fprintf(stderr, "rendering on %d device(s) failed: %d, %s\n", devices, errno, rtGetErrorDesc()); return 1; }
+    printf("...ray-tracing on %d device(s) done. Time per frame: %.6f seconds\n", devices, secs);
+    errno = 0;
+    rtBitmapSave(out, opt['o'], 24);
+    if (errno == E_IO || errno == E_MEMORY || errno == E_INVALID_BPP) { fprintf(stderr, "problem while saving result image: %d, %s\n", errno, rtGetErrorDesc()); return 1; }
+    rtBitmapDestroy(&out);
+    rtCameraDestroy(&cam);
+    rtSceneDestroy(&scene);
+    return 0;
+  }
 
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);

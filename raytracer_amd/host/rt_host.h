@@ -131,6 +131,12 @@ typedef struct _RT_SceneFlat {
 RT_SceneFlat *rtSceneFlatten(const RT_Scene *scene);
 void rtSceneFlatFree(RT_SceneFlat **flat);
 void rtCameraFlatten(const RT_Camera *cam, rtgpu_camera *out);
+/* Which tiles go to which device when a frame is split over ndev GPUs, and where each device's block starts in the
+ * gathered buffer (tiles[ndev], first_pixel[ndev + 1]); see scene.c. */
+void rtTilePlan(int32_t width, int32_t height, int ndev, int64_t *tiles, int64_t *first_pixel);
+/* multigpu.c (librtmulti.so, needs RCCL): `frames` frames on devices 0..ndev-1 of this node, one process; returns the
+ * last frame.  seconds (optional): wall time per frame after the first. */
+RT_Bitmap *rtHostRenderDevices(RT_Scene *scene, RT_Camera *camera, int ndev, int frames, double *seconds);
 /* The loaders' decimal parser (exact short path, strtof otherwise), exported for the tests. */
 float rtParseFloat(const char *text, int *consumed);
 

@@ -509,6 +509,21 @@ void rtSceneFlatFree(RT_SceneFlat **flat) {
   *flat = NULL;
 }
 
+/* Tile bookkeeping of a frame split over ndev devices: the image is cut into 8x8-pixel tiles numbered row-major, tile t
+ * belongs to device t % ndev.  tiles[r] = number of tiles of device r; first_pixel[r] = offset, in pixels, of device r's
+ * block in the rank-major gathered buffer (first_pixel[ndev] = its total length): the layout rtgpu_untile reads. */
+void rtTilePlan(int32_t width, int32_t height, int ndev, int64_t *tiles, int64_t *first_pixel) {
+  const int64_t ntiles = (int64_t)((width + 7) / 8) * ((height + 7) / 8);
+  int64_t at = 0;
+  int r;
+  for (r = 0; r < ndev; r++) {
+    tiles[r] = r < ntiles ? (ntiles - r + ndev - 1) / ndev : 0;
+    first_pixel[r] = at;
+    at += tiles[r] * 64;
+  }
+  first_pixel[ndev] = at;
+}
+
 void rtCameraFlatten(const RT_Camera *cam, rtgpu_camera *out) {
   int k;
   for (k = 0; k < 3; k++) { out->ob[k] = cam->ob[k]; out->ul[k] = cam->ul[k]; out->bl[k] = cam->bl[k]; out->ur[k] = cam->ur[k]; }

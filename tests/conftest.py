@@ -16,3 +16,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def pow_free_pixels(scene, ids):
+    """Pixels whose colour involves no pow(): the only operation of the path whose result may differ between the GPU's
+    math library and glibc (src/raytrace.c:227 calls it when ks > 0).  True where the frame has no surface with ks > 0
+    at all, where the primary ray hit nothing, or hit a surface with ks = 0 that spawns no secondary ray."""
+    import numpy as np
+    surf = scene.desc.surfaces
+    ks = np.array([surf[i].ks for i in range(scene.ns)])
+    kr = np.array([surf[i].kr for i in range(scene.ns)])
+    kt = np.array([surf[i].kt for i in range(scene.ns)])
+    sid = scene.sids()
+    if not (ks[np.unique(sid)] > 0).any():
+        return np.ones(ids.shape, bool)
+    hit = ids >= 0
+    s = sid[np.clip(ids, 0, None)]
+    return ~hit | ((ks[s] == 0) & (kr[s] == 0) & (kt[s] == 0))

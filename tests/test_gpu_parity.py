@@ -17,6 +17,7 @@ import pytest
 import raytracer_amd as rt
 from raytracer_amd.api import rgba_to_u8
 from oracle import oracle as O
+from conftest import pow_free_pixels
 
 pytestmark = pytest.mark.gpu
 
@@ -83,6 +84,12 @@ def test_frame_matches_reference_golden(renderer, name):
     print("%s: raw colour bit-exact on %.4f of pixels, max rel diff %.3g" % (name, exact, rel.max() if rel.size else 0))
     assert np.isfinite(g["rgb"][clean]).all() == np.isfinite(o["rgb"][clean]).all()
     assert rel.max() < 1e-4  # only pow() (ocml vs glibc) may differ, by an ulp of the double result
+    # ... and where no pow() is involved (ks = 0: all of temple and test, parts of the others) every bit is the oracle's
+    nopow = pow_free_pixels(scene, g["ids"]) & clean
+    assert (g["rgb"].view(np.uint32) == o["rgb"].view(np.uint32))[nopow].all(), "a colour without pow() differs from the oracle"
+    if name in ("temple", "test"):
+        assert nopow.all() and exact == 1.0
+    assert exact >= 0.999  # observed: 1.0 on every case (the double results of the two pow() round to the same float)
     # 3. the 8-bit image against the reference's: within 1/255 per channel
     if tex:
         mm = o["minmax"]  # the reference's own min/max is polluted by its uninitialised samples; share one

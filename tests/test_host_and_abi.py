@@ -179,3 +179,29 @@ def test_chunk_limit_keeps_items_inside_32_bit_tickets():
     # the case of the review: a scene without secondary rays, 26 lights, more than 67 M pixels in one chunk
     assert int(L.rtgpu_chunk_tile_limit(0, 1, 26)) * 64 * 26 < 2 ** 32
     assert int(L.rtgpu_chunk_tile_limit(3, 5, 6)) == -1 and int(L.rtgpu_chunk_tile_limit(1, 6, 6)) == -1
+
+
+@pytest.mark.parametrize("w,h", [(3840, 2160), (97, 61), (8, 8), (7680, 4320), (50, 100), (5, 3)])
+def test_tile_plan_of_the_c_multi_gpu_host(w, h):
+    """rtTilePlan (host/scene.c), the bookkeeping of `raytrace --devices N`: tiles per device and the offsets of the
+    devices' blocks in the gathered buffer are a partition of the image's tiles, in the layout the Python path
+    (raytracer_amd/dist.py) and rtgpu_untile use."""
+    from raytracer_amd import dist as D
+    H = rt.host_lib()
+    H.rtTilePlan.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    H.rtTilePlan.restype = None
+    ntiles = D.tiles_of(w, h)
+    for ndev in (1, 2, 3, 4, 8, 64):
+        tiles = (ctypes.c_int64 * ndev)()
+        first = (ctypes.c_int64 * (ndev + 1))()
+        H.rtTilePlan(w, h, ndev, tiles, first)
+        assert list(tiles) == [D.tile_count(ntiles, r, ndev) for r in range(ndev)]
+        assert sum(tiles) == ntiles and first[0] == 0 and first[ndev] == ntiles * 64
+        assert all(first[r + 1] - first[r] == tiles[r] * 64 for r in range(ndev))
+        # the gathered layout de-interleaves to the image: a frame whose pixels hold their own index survives the round trip
+        if w * h <= 97 * 61:
+            img = np.arange(w * h, dtype=np.int64).reshape(h, w)
+            parts = [D.split_tiles_reference(img, r, ndev).reshape(-1) for r in range(ndev)]
+            assert all(len(p) == tiles[r] * 64 for r, p in enumerate(parts))
+            back = D.untile_reference(np.concatenate(parts), ndev, w, h)
+            assert np.array_equal(back, img)
