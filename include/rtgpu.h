@@ -110,6 +110,9 @@ typedef struct rtgpu_counters {
   /* Exact tests (src/intersection.c:58-86) that ran to their last line, counted per ray (lane), not per wavefront:
    * 45 flops each in the reference's accounting (only with "count" = 1). */
   int64_t nearest_full_tests, shadow_full_tests;
+  /* Chunks of tiles the last rtgpu_render call cut this rank's share into, and how many of them it rendered a second
+   * time because a queue of secondary rays, sized from earlier chunks, was too small (option "queue_sizing"). */
+  int64_t chunks, chunks_rerendered;
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP
@@ -140,6 +143,10 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default:
  * what each walk kernel is compiled for, 20 and 24), "pipeline" (default 1: rtgpu_frame_begin builds on its
  * own stream into the buffers the previous frame does not use, overlapping that frame's kernels; 0: on the context's stream),
+ * "queue_sizing" (default 1: in scenes with reflective or transparent surfaces the queues of the secondary rays are sized from
+ * what the scene's chunks produce, which costs one host synchronisation per chunk, and a chunk whose queues turn out too small
+ * is rendered again with worst-case queues; 0: always worst case, 31 nodes per pixel at depth 5, no synchronisation),
+ * "queue_margin" (default 1500: queues are planned for the largest ratio seen so far x 1.5; in permille),
  * "filter" (default 1; 0 switches off the conservative triangle filter and the batch culling of the
  * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */
 int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);

@@ -1021,11 +1021,18 @@ RT_D Ray primary_ray(const PrimaryP &pp, const GridP &g, int idx, bool with_voxe
   return ry;
 }
 // Start of a chunk: resets its control block (queue lengths, tickets, statistics); n0 rays at level 0.
-__global__ void __launch_bounds__(256) k_chunk_init(int n0, Ctl *__restrict__ ctl) {
+__global__ void __launch_bounds__(256) k_chunk_init(int n0, QueueCaps caps, Ctl *__restrict__ ctl) {
   static_assert(sizeof(Ctl) % 4 == 0 && sizeof(Ctl) / 4 <= 256, "one thread per word of the control block");
   if (threadIdx.x < sizeof(Ctl) / 4) reinterpret_cast<uint32_t *>(ctl)[threadIdx.x] = 0u;
   __syncthreads();
   if (threadIdx.x == 0) ctl->count[0] = n0;
+  if (threadIdx.x <= kMaxLevels) ctl->cap[threadIdx.x] = caps.cap[threadIdx.x];
+}
+// Entries of level L's queue: what the level above produced, cut at the queue's capacity (the host sizes the queues of
+// the secondary rays from what earlier chunks produced and renders a chunk again, with larger queues, if one was cut).
+RT_D int queue_len(const Ctl *__restrict__ ctl, int level) {
+  const int n = ctl->count[level], cap = ctl->cap[level];
+  return n < cap ? n : cap;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1049,7 +1056,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
   float *slice = lds_batches[threadIdx.x >> 6];
   const bool occ_in_lds = load_occupancy(g, occ_s);
   const int lane = lane_id();
-  const int nrays = ctl->count[level];
+  const int nrays = queue_len(ctl, level);
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
   unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0, nFull = 0;
@@ -1246,9 +1253,12 @@ __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__re
                                              Node *__restrict__ nodes, SOrigin *__restrict__ sorg, const float *__restrict__ geom,
                                              Ray *__restrict__ next_rays, Ctl *__restrict__ ctl, int level,
                                              int node_base, int next_base, int next_cap, bool spawn, PrimaryP prim) {
-  const int n = ctl->count[level];
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = queue_len(ctl, level);
   const int lane = lane_id();
+  // block-stride loop: the launch is sized for the queue's capacity, cut at a few thousand blocks; a block's
+  // wavefronts stay together (the child slots come from a ballot)
+  for (int idx0 = blockIdx.x * blockDim.x; idx0 < n; idx0 += gridDim.x * blockDim.x) {
+  const int idx = idx0 + threadIdx.x;
   const bool valid = idx < n;
   Hit h; h.tri = -2;
   Ray ry;
@@ -1307,6 +1317,7 @@ __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__re
     so.p[0] = nd.p[0]; so.p[1] = nd.p[1]; so.p[2] = nd.p[2]; so.tri = nd.tri;
     sorg[node_base + idx] = so;
   }
+  }
 }
 
 // Replay of the order in which the reference consumes rand() for planar lights (raytrace.c:245-251).
@@ -1319,13 +1330,14 @@ __global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__re
 //   k_assign_ranks   top level first: start of each child's subtree, then the node's own rank
 __global__ void __launch_bounds__(256) k_subtree_hits(const Node *__restrict__ nodes, int32_t *__restrict__ size,
                                                       const Ctl *__restrict__ ctl, int level, int node_base) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ctl->count[level]) return;
-  const Node v = nodes[node_base + idx];
-  int32_t s = v.tri >= 0 ? 1 : 0;
-  if (v.refl >= 0) s += size[v.refl];
-  if (v.refr >= 0) s += size[v.refr];
-  size[node_base + idx] = s;
+  const int n = queue_len(ctl, level);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const Node v = nodes[node_base + idx];
+    int32_t s = v.tri >= 0 ? 1 : 0;
+    if (v.refl >= 0) s += size[v.refl];
+    if (v.refr >= 0) s += size[v.refr];
+    size[node_base + idx] = s;
+  }
 }
 // Pixel-order scan of the level-0 subtree sizes of the whole image.  sizes: per rank `per_rank` entries, tile-major in
 // the rank's own tile numbering (tile t of the image is tile t / world of rank t % world); the ranks of this rank's own
@@ -1368,15 +1380,16 @@ __global__ void __launch_bounds__(1024) k_tree_starts(int w, int h, int tiles_x,
 __global__ void __launch_bounds__(256) k_assign_ranks(const Node *__restrict__ nodes, const int32_t *__restrict__ size,
                                                       int32_t *__restrict__ rank, const Ctl *__restrict__ ctl, int level,
                                                       int node_base) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ctl->count[level]) return;
-  const int gidx = node_base + idx;
-  const Node v = nodes[gidx];
-  const int32_t start = rank[gidx];  // set by k_tree_starts (level 0) or by the parent
-  const int32_t a = v.refl >= 0 ? size[v.refl] : 0, b = v.refr >= 0 ? size[v.refr] : 0;
-  if (v.refl >= 0) rank[v.refl] = start;
-  if (v.refr >= 0) rank[v.refr] = start + a;
-  rank[gidx] = start + a + b;
+  const int n = queue_len(ctl, level);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const int gidx = node_base + idx;
+    const Node v = nodes[gidx];
+    const int32_t start = rank[gidx];  // set by k_tree_starts (level 0) or by the parent
+    const int32_t a = v.refl >= 0 ? size[v.refl] : 0, b = v.refr >= 0 ? size[v.refr] : 0;
+    if (v.refl >= 0) rank[v.refl] = start;
+    if (v.refr >= 0) rank[v.refr] = start + a;
+    rank[gidx] = start + a + b;
+  }
 }
 
 // Position of shadow-query slot `slot` of a shaded hit: a point light, or sample d of planar light c
@@ -1414,7 +1427,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   float *slice = lds_batches[threadIdx.x >> 6];
   const bool occ_in_lds = load_occupancy(g, occ_s);
   const int lane = lane_id();
-  const int n = ctl->count[level];
+  const int n = queue_len(ctl, level);
   const long long total = (long long)n * sp.nslots;
   const uint32_t *__restrict__ cstart = g.cell_start;
   const TriRec *__restrict__ recs = g.cell_tris;
@@ -1660,13 +1673,16 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
                                                     float *__restrict__ colors, Ctl *__restrict__ ctl, int level,
                                                     int node_base, float *__restrict__ fb_rgb, int32_t *__restrict__ fb_ids,
                                                     long long fb_base, float *__restrict__ partial, PrimaryP prim) {
-  const int n = ctl->count[level];
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = queue_len(ctl, level);
+  const bool fold = level == 0 && partial != nullptr;  // level 0 also folds the colour range of the block's pixels
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
+  // block-stride loop (the launches of the levels below 0 are sized for the queue's capacity, cut at a few thousand blocks)
+  for (int idx0 = blockIdx.x * blockDim.x; idx0 < n; idx0 += gridDim.x * blockDim.x) {
+  const int idx = idx0 + threadIdx.x;
   const bool valid = idx < n;
-  if (!valid && (level != 0 || partial == nullptr)) return;  // (level 0 folds its colour range block by block below)
-  const int gidx = node_base + (valid ? idx : 0);
-  Node nd = nodes[gidx];
-  if (!valid) nd.tri = -2;
+  if (!valid) continue;
+  const int gidx = node_base + idx;
+  const Node nd = nodes[gidx];
   f3 res = mk3(0.0f, 0.0f, 0.0f);
   if (nd.tri >= 0) {
     const SurfaceD sf = sp.surf[sp.tri_sid[nd.tri]];
@@ -1718,14 +1734,14 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
       fb_ids[p] = nd.tri >= 0 ? nd.tri : -1;
     }
   }
-  if (level == 0 && partial != nullptr) {
+  if (fold && nd.tri >= -1) {  // (a pixel whose ray never entered the grid takes no part, raytrace.c:381-382)
+    const float c[3] = {res.x, res.y, res.z};
+    mm_fold(mn, mx, c, c);
+  }
+  }
+  if (fold) {
     // per-channel min/max over the traced pixels of this block (raytrace.c:396-399): partial[blockIdx.x][6]
     __shared__ float sm[4][6];
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
-    if (nd.tri >= -1) {
-      const float c[3] = {res.x, res.y, res.z};
-      mm_fold(mn, mx, c, c);
-    }
     for (int off = 32; off > 0; off >>= 1) {
       float omn[3], omx[3];
 #pragma unroll
@@ -1754,7 +1770,7 @@ __global__ void __launch_bounds__(1024) k_minmax_final(const float *__restrict__
   if (ctl != nullptr) {
     const int t = threadIdx.x;
     if (t < kStatCount) totals[t] += ctl->stat[t];
-    else if (t < kStatCount + kMaxLevels) totals[t] += (unsigned long long)ctl->count[t - kStatCount];
+    else if (t < kStatCount + kMaxLevels) totals[t] += (unsigned long long)queue_len(ctl, t - kStatCount);
   }
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) mm_fold(mn, mx, partial + 6 * b, partial + 6 * b + 3);
@@ -1789,7 +1805,7 @@ __global__ void k_minmax_init(float *minmax) {
 __global__ void k_fold_stats(const Ctl *__restrict__ ctl, unsigned long long *__restrict__ totals) {
   int t = threadIdx.x;
   if (t < kStatCount) totals[t] += ctl->stat[t];
-  else if (t < kStatCount + kMaxLevels) totals[t] += (unsigned long long)ctl->count[t - kStatCount];
+  else if (t < kStatCount + kMaxLevels) totals[t] += (unsigned long long)queue_len(ctl, t - kStatCount);
 }
 
 // ------------------------------------------------------------------------------------------------

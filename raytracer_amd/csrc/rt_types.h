@@ -141,12 +141,14 @@ struct ShadeP {
 
 // Device-side control block of one chunk: queue lengths, tickets of the persistent kernels, statistics.
 struct Ctl {
-  int32_t count[kMaxLevels + 1];        // rays/nodes per level
+  int32_t count[kMaxLevels + 1];        // rays/nodes per level as produced; what was produced beyond cap[] is dropped
+  int32_t cap[kMaxLevels + 1];          // capacity of every level's queue: readers use min(count, cap) (queue_len)
   uint32_t ticket_nearest[kMaxLevels];
   uint32_t ticket_shadow[kMaxLevels];
   uint32_t pad;
   unsigned long long stat[32];
 };
+struct QueueCaps { int32_t cap[kMaxLevels + 1]; };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
             kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests,
             kNearStage2, kNearStage3, kNearExact, kShadStage2, kShadStage3, kShadExact,

@@ -97,6 +97,15 @@ struct rtgpu_ctx {
   ShadeP shade = {};
   // chunk queues
   size_t chunk_tiles_cap = 0;
+  // Sizing of the secondary-ray queues.  A hit spawns up to `fan` rays, so level L could hold fan^L entries per pixel
+  // (31 nodes per pixel at fan 2); scenes spawn far fewer (ulica: 2.9).  fac[L] = entries of level L per pixel the queues
+  // are planned for; fac_alloc[L] what the allocated queues were planned for; ratio[L] the largest count[L] / count[0]
+  // a chunk of this scene has produced so far (known after a first, small chunk with worst-case queues).
+  double fac[kMaxLevels] = {1, 0, 0, 0, 0}, fac_alloc[kMaxLevels] = {0, 0, 0, 0, 0}, ratio[kMaxLevels] = {1, 0, 0, 0, 0};
+  bool have_ratio = false;
+  int64_t last_chunks = 0, last_rerendered = 0;  // of the last rtgpu_render call
+  int queue_margin_permille = 1500;  // option "queue_margin": planned entries = observed ratio x this / 1000 (+ 0.02 per pixel)
+  bool adaptive_queues = true;  // option "queue_sizing": 1 = from what the scene produces (one host sync per chunk), 0 = worst case
   size_t cap[kMaxLevels] = {0, 0, 0, 0, 0}, base[kMaxLevels] = {0, 0, 0, 0, 0}, total_nodes = 0;
   Ray *d_rays[kMaxLevels] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   Hit *d_hits = nullptr;  // sized for the largest level
@@ -226,7 +235,7 @@ template <typename F>
 int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
   size_t total = 0, maxcap = 0;
   for (int L = 0; L < c->levels; L++) {
-    c->cap[L] = L == 0 ? tiles * kTilePixels : c->cap[L - 1] * (size_t)c->fan;
+    c->cap[L] = L == 0 ? tiles * kTilePixels : (size_t)ceil((double)(tiles * kTilePixels) * c->fac[L]) + 64;
     c->base[L] = total;
     total += c->cap[L];
     maxcap = c->cap[L] > maxcap ? c->cap[L] : maxcap;
@@ -246,8 +255,25 @@ int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
   return RTGPU_OK;
 }
 
+// Factors of the worst case (every hit spawns `fan` rays), and of the current knowledge of the scene.
+void worst_case_factors(rtgpu_ctx *c) {
+  double f = 1.0;
+  for (int L = 0; L < kMaxLevels; L++) { c->fac[L] = L < c->levels ? f : 0.0; f *= c->fan; }
+}
+void observed_factors(rtgpu_ctx *c) {
+  double worst = 1.0;
+  for (int L = 0; L < kMaxLevels; L++) {
+    const double want = L == 0 ? 1.0 : c->ratio[L] * (c->queue_margin_permille * 0.001) + 0.02;  // default: half as much again as the fullest chunk so far
+    c->fac[L] = L < c->levels ? (want < worst ? want : worst) : 0.0;
+    worst *= c->fan;
+  }
+}
+
 int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
-  if (tiles <= c->chunk_tiles_cap) return RTGPU_OK;
+  bool fits = tiles <= c->chunk_tiles_cap;
+  for (int L = 0; L < c->levels && fits; L++)  // (queues planned for more tiles hold more entries per level than asked for here)
+    fits = (double)c->chunk_tiles_cap * c->fac_alloc[L] >= (double)tiles * c->fac[L];
+  if (fits) return RTGPU_OK;
   c->chunk_tiles_cap = 0;
   int rc = plan_queues(c, tiles, [&](void **slot, size_t bytes) {
     if (*slot) { (void)hipFree(*slot); *slot = nullptr; }
@@ -256,6 +282,7 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
   });
   if (rc) return rc;
   c->chunk_tiles_cap = tiles;
+  for (int L = 0; L < kMaxLevels; L++) c->fac_alloc[L] = c->fac[L];
   return RTGPU_OK;
 }
 
@@ -294,14 +321,15 @@ int ensure_rand(rtgpu_ctx *c, size_t need) {
 }
 
 size_t bytes_per_tile(const rtgpu_ctx *c) {
-  size_t nodes = 0, capL = kTilePixels, maxcap = 0;
+  double nodes = 0, maxcap = 0;
   for (int L = 0; L < c->levels; L++) {
-    if (L > 0) capL *= (size_t)c->fan;
+    const double capL = kTilePixels * c->fac[L] + (L > 0 ? 1.0 : 0.0);
     nodes += capL;
     maxcap = capL > maxcap ? capL : maxcap;
   }
-  return nodes * (sizeof(Ray) + sizeof(Node) + sizeof(SOrigin) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) -
-         kTilePixels * sizeof(Ray) + maxcap * sizeof(Hit) + kTilePixels * 4;  // (no ray queue for level 0)
+  const double b = nodes * (double)(sizeof(Ray) + sizeof(Node) + sizeof(SOrigin) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) -
+                   (double)(kTilePixels * sizeof(Ray)) + maxcap * (double)sizeof(Hit) + kTilePixels * 4.0;  // (no ray queue for level 0)
+  return (size_t)ceil(b);
 }
 
 }  // namespace
@@ -410,6 +438,8 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
+  else if (!strcmp(name, "queue_margin")) { if (value < 1 || value > 100000) return fail(c, RTGPU_E_INVALID_PARAM, "queue_margin out of range"); c->queue_margin_permille = (int)value; }
+  else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
@@ -466,6 +496,9 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   }
   c->levels = c->fan > 0 ? kMaxLevels : 1;
   c->chunk_tiles_cap = 0;
+  c->have_ratio = false;
+  for (int L = 0; L < kMaxLevels; L++) c->ratio[L] = L == 0 ? 1.0 : 0.0;
+  worst_case_factors(c);
   int rc;
   if ((rc = dev_alloc(c, &c->d_verts, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->d_geom, (size_t)s->nt * 9)) ||
       (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_filt, (size_t)s->nt * kRecFloats)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
@@ -644,6 +677,13 @@ int64_t rtgpu_tile_count(const rtgpu_ctx *c, int rank, int world) {
 
 namespace {
 
+// Blocks of the one-thread-per-node kernels: level 0 has exactly n0 entries; the levels below are launched for their
+// queue's capacity, cut at 4096 blocks: the kernels loop, and the entries actually there are usually far fewer.
+unsigned node_blocks(size_t cap, int level) {
+  const size_t b = (cap + 255) / 256;
+  return (unsigned)(level == 0 || b < 4096 ? (b ? b : 1) : 4096);
+}
+
 // One chunk of tiles, first half: primary rays, then nearest-hit walk and hit kernel level by level
 // (raytrace.c:170-204); with planar lights also the number of shaded hits in every node's subtree.
 int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
@@ -655,7 +695,9 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   queued.on = 0;
   {
     Span sp(c, W_PRIMARY);  // the control block; the primary rays themselves are computed where they are used
-    KLAUNCH(c, k_chunk_init, dim3(1), dim3(256), c->stream, n0, c->d_ctl);
+    QueueCaps caps;
+    for (int L = 0; L <= kMaxLevels; L++) caps.cap[L] = L == 0 ? n0 : L < c->levels ? (int32_t)c->cap[L] : 0;
+    KLAUNCH(c, k_chunk_init, dim3(1), dim3(256), c->stream, n0, caps, c->d_ctl);
   }
   for (int L = 0; L < c->levels; L++) {
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
@@ -669,7 +711,7 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
     {
       Span sp(c, W_HIT);
       const bool spawn = L + 1 < c->levels;
-      KLAUNCH(c, k_hit, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
+      KLAUNCH(c, k_hit, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,
                          c->d_nodes, c->d_sorg, c->d_geom, spawn ? c->d_rays[L + 1] : nullptr, c->d_ctl, L, (int)c->base[L],
                          spawn ? (int)c->base[L + 1] : 0, spawn ? (int)c->cap[L + 1] : 0, spawn, L == 0 ? c->prim : queued);
     }
@@ -677,7 +719,7 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   if (c->npl > 0) {
     for (int L = c->levels - 1; L >= 0; L--) {
       const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-      KLAUNCH(c, k_subtree_hits, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->d_nodes, c->d_size, c->d_ctl, L, (int)c->base[L]);
+      KLAUNCH(c, k_subtree_hits, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->d_nodes, c->d_size, c->d_ctl, L, (int)c->base[L]);
     }
   }
   return RTGPU_OK;
@@ -691,7 +733,7 @@ int chunk_ranks(rtgpu_ctx *c, int n0, const int32_t *sizes, int64_t per_rank, in
                      world, rank, c->d_rank);
   for (int L = 0; L < c->levels; L++) {
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-    KLAUNCH(c, k_assign_ranks, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->d_nodes, c->d_size, c->d_rank, c->d_ctl, L, (int)c->base[L]);
+    KLAUNCH(c, k_assign_ranks, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->d_nodes, c->d_size, c->d_rank, c->d_ctl, L, (int)c->base[L]);
   }
   if (c->fan > 0) {
     // secondary hits draw random numbers too: the table must cover every shaded hit of the frame (a host sync,
@@ -726,7 +768,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   for (int L = c->levels - 1; L >= 0; L--) {
     Span sp(c, W_ACCUM);
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-    KLAUNCH(c, k_accumulate, dim3((unsigned)((capL + 255) / 256)), dim3(256), c->stream, c->shade, c->d_rays[L], c->d_nodes,
+    KLAUNCH(c, k_accumulate, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->shade, c->d_rays[L], c->d_nodes,
                        c->d_ts, (long long)c->total_nodes, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
                        L == 0 ? c->d_partial : nullptr,  // level 0 (the last one) also folds the colour range of its blocks
                        L == 0 ? c->prim : queued);
@@ -739,7 +781,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   return RTGPU_OK;
 }
 
-// Tiles per chunk for this rank's share, and the queues for it.
+// Tiles per chunk for this rank's share (at most `most`), and the queues for it, with the current sizing factors.
 int plan_chunks(rtgpu_ctx *c, int64_t ntiles, bool whole, int64_t *chunk_out) {
   size_t per_tile = bytes_per_tile(c);
   int64_t chunk = (int64_t)(c->chunk_bytes / (int64_t)per_tile);
@@ -755,6 +797,22 @@ int plan_chunks(rtgpu_ctx *c, int64_t ntiles, bool whole, int64_t *chunk_out) {
   return ensure_chunk(c, (size_t)chunk);
 }
 
+// After the first half of a chunk: how many rays every level held (one host synchronisation).  Updates the scene's
+// observed ratios; *cut = some queue was too small for what the level above produced.
+int check_queues(rtgpu_ctx *c, int n0, bool *cut) {
+  int32_t count[kMaxLevels + 1];
+  HIPCHK(c, hipMemcpyAsync(count, c->d_ctl, sizeof count, hipMemcpyDeviceToHost, c->stream));  // Ctl starts with count[]
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *cut = false;
+  for (int L = 1; L < c->levels; L++) {
+    const double r = (double)count[L] / (double)(n0 > 0 ? n0 : 1);
+    if (r > c->ratio[L]) c->ratio[L] = r;
+    if ((size_t)count[L] > c->cap[L]) *cut = true;
+  }
+  c->have_ratio = true;
+  return RTGPU_OK;
+}
+
 }  // namespace
 
 int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax) {
@@ -767,15 +825,33 @@ int rtgpu_render(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t *d_ids
   KLAUNCH(c, k_frame_init, dim3(1), dim3(64), c->stream, d_minmax, c->d_totals);
   c->split_tiles = -1;
   if (ntiles == 0) return RTGPU_OK;
-  int64_t chunk = 0;
-  int rc = plan_chunks(c, ntiles, c->npl > 0, &chunk);
-  if (rc) return rc;
   c->grid.slack = c->filter ? 0.0f : INFINITY;
-  for (int64_t t0 = 0; t0 < ntiles; t0 += chunk) {
-    const int nt_chunk = (int)((ntiles - t0) < chunk ? (ntiles - t0) : chunk);
+  // Scenes with secondary rays: the queues of the levels below 0 are sized from what the scene's chunks have produced so
+  // far (a first chunk of at most 2048 tiles runs with worst-case queues to find out), checked after the first half of
+  // every chunk; a chunk whose queues were cut is rendered again with worst-case queues.  Planar lights need the
+  // whole share in one chunk with its random numbers: worst case.  Scenes without secondary rays have nothing to size.
+  const bool adaptive = c->adaptive_queues && c->fan > 0 && c->npl == 0;
+  bool worst_once = false;
+  int rc;
+  c->last_chunks = c->last_rerendered = 0;
+  for (int64_t t0 = 0; t0 < ntiles;) {
+    const bool pilot = adaptive && !c->have_ratio;
+    if (adaptive && !pilot && !worst_once) observed_factors(c); else worst_case_factors(c);
+    int64_t chunk = 0;
+    const int64_t left = ntiles - t0;
+    if ((rc = plan_chunks(c, pilot && left > 2048 ? 2048 : left, c->npl > 0, &chunk))) return rc;
+    const int nt_chunk = (int)chunk;
     if ((rc = chunk_trace(c, t0, nt_chunk, rank, world))) return rc;
+    if (adaptive) {
+      bool cut = false;
+      if ((rc = check_queues(c, nt_chunk * kTilePixels, &cut))) return rc;
+      if (cut) { worst_once = true; c->last_rerendered++; continue; }  // (only a chunk sized from earlier ones can be cut; worst-case queues hold everything)
+      worst_once = false;
+    }
     if (c->npl > 0 && (rc = chunk_ranks(c, nt_chunk * kTilePixels, c->d_size, 0, 0, 1, -1))) return rc;
     if ((rc = chunk_shade(c, t0, nt_chunk, d_rgb, d_ids, d_minmax))) return rc;
+    t0 += chunk;
+    c->last_chunks++;
   }
   mark_released(c);
   HIPCHK(c, hipGetLastError());
@@ -796,6 +872,7 @@ int rtgpu_render_static(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t
   if (ntiles > rtgpu_chunk_tile_limit(c->fan, c->levels, c->shade.nslots))
     return fail(c, RTGPU_E_UNSUPPORTED, "rtgpu_render_static: this rank's share has more work items than one chunk can number; use rtgpu_render");
   const QueueSet own = take_queues(c);
+  worst_case_factors(c);  // (sizing from earlier chunks would need a look at the queue lengths from the host in mid-frame)
   size_t need = 0;
   (void)plan_queues(c, (size_t)ntiles, [&](void **, size_t bytes) { need += (bytes + 255) & ~(size_t)255; return (int)RTGPU_OK; });
   if (need > kScratchBytes) {
@@ -841,6 +918,7 @@ int rtgpu_render_trace(rtgpu_ctx *c, int rank, int world) {
   c->split_tiles = -1;
   if (ntiles == 0) { c->split_tiles = 0; c->split_rank = rank; c->split_world = world; return RTGPU_OK; }
   int64_t chunk = 0;
+  worst_case_factors(c);
   int rc = plan_chunks(c, ntiles, true, &chunk);
   if (rc) return rc;
   c->grid.slack = c->filter ? 0.0f : INFINITY;
@@ -964,6 +1042,7 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   out->nearest_visits = (int64_t)h[kNearVisits]; out->shadow_visits = (int64_t)h[kShadVisits];
   out->nearest_batches = (int64_t)h[kNearBatches]; out->nearest_batches_culled = (int64_t)h[kNearCulled];
   out->shadow_batches = (int64_t)h[kShadBatches]; out->shadow_batches_culled = (int64_t)h[kShadCulled];
+  out->chunks = c->last_chunks; out->chunks_rerendered = c->last_rerendered;
   out->nearest_full_tests = (int64_t)h[kNearFull]; out->shadow_full_tests = (int64_t)h[kShadFull];
   return RTGPU_OK;
 }
