@@ -52,6 +52,13 @@ RT_D bool wave_any(bool p) {
   return m != 0;
 }
 
+// The lanes in which the predicate holds, through an opaque scalar register like wave_any.
+RT_D unsigned long long wave_mask(bool p) {
+  unsigned long long m = __ballot(p);
+  asm volatile("" : "+s"(m));
+  return m;
+}
+
 RT_D float lane_bcast(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 RT_D f3 lane_bcast3(f3 v, int l) { return mk3(lane_bcast(v.x, l), lane_bcast(v.y, l), lane_bcast(v.z, l)); }
 
@@ -242,6 +249,8 @@ RT_D bool box_test_ray(f3 c, float delta_and_flag, f3 hw, float W, f3 r, f3 m, f
 __device__ unsigned long long g_phase[16];
 #ifdef RT_HIST
 __device__ unsigned long long g_hist[2][2][9];  // [walk][0 = batches, 1 = (lane, record) pairs][records of the batch some lane passed]
+__device__ unsigned long long g_mode[2][3][4];  // [walk][cell, lane, ray mode][visits, wave-level record tests, lane-level record tests, rays in the group]
+__device__ unsigned long long g_cand[2][4];     // [walk][headers looked at, passed the bundle's box test, kept by the ray-by-ray test, cell visits]
 #endif
 // Per-ticket log of the walk kernels, only in builds with -DRT_TICKETS (tools/tickets.py): shader clocks from
 // taking the ticket to its last result, cell visits, batches that reached the ray-by-ray test, records tested.
@@ -330,9 +339,12 @@ RT_D void wait_staged() {
 //                      lane for some of them does the wavefront leave the straight-line path and run
 //   f(record, index)   the full test on those records, in list order, checking
 //   more()             (wave-uniform) after each: false = stop.
+// own_sub, own_mask: for a ticket shared by own_mask + 1 wavefronts, only the header chunks (256 records) whose index
+// & own_mask equals own_sub are looked at (0, 0: all of them).
 template <typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
-                      bool transparent_counts_anywhere, Phases &ph, C &&cull, T &&tally, B &&batch, P &&pass1, F &&f, G &&more) {
+                      bool transparent_counts_anywhere, uint32_t own_sub, uint32_t own_mask, Phases &ph, C &&cull, T &&tally, B &&batch,
+                      P &&pass1, F &&f, G &&more) {
   ph.template end<1>();
   float *hs = slice;                             // kHdrChunk headers
   float *rs = slice + kHdrChunk * kHdrFloats;    // two buffers of kBatch records
@@ -340,6 +352,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
   const float4 *hsrc = reinterpret_cast<const float4 *>(g.cell_hdrs + hbeg);
   const uint32_t nb = (cnt + kBatch - 1) / kBatch;
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
+    if (((h0 / kHdrChunk) & own_mask) != own_sub) continue;  // a shared ticket: another wavefront tests this part of the list
     const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
     static_assert(kHdrChunk * kHdrFloats / 4 <= 192, "up to three 16-byte loads per lane stage a header chunk");
     if (lane < 3 * nh) glds16(hsrc + 3 * h0 + lane, hs);
@@ -370,17 +383,27 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     __builtin_amdgcn_wave_barrier();
     const unsigned long long candidates = __ballot(maybe);
     tally(nh, nh - __popcll(candidates));
+#ifdef RT_HIST
+    if (lane == 0) { atomicAdd(&g_cand[transparent_counts_anywhere ? 1 : 0][0], (unsigned long long)nh); atomicAdd(&g_cand[transparent_counts_anywhere ? 1 : 0][1], (unsigned long long)__popcll(candidates)); }
+#endif
     // ray by ray: which of the candidates can any ray of the wavefront meet
     unsigned long long kept = 0;
     for (unsigned long long cm = candidates; cm != 0; cm &= cm - 1) {
       const int b = __ffsll(cm) - 1;
       const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, -+delta
       const v4f hw = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);  // h + W, W
-      const bool keep = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hw.x, hw.y, hw.z), hw.w);
+      const unsigned long long hit_by = cull(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hw.x, hw.y, hw.z), hw.w);  // the rays that may meet the batch's box
+      const bool keep = hit_by != 0;
+#ifdef RT_HIST
+      if (lane == 0 && keep) atomicAdd(&g_cand[transparent_counts_anywhere ? 1 : 0][3], (unsigned long long)__popcll(hit_by));
+#endif
       tally(0, keep ? 0 : 1);
       tally(-1, 0);  // one more batch reached the ray-by-ray test
       if (keep) kept |= 1ull << b;
     }
+#ifdef RT_HIST
+    if (lane == 0) atomicAdd(&g_cand[transparent_counts_anywhere ? 1 : 0][2], (unsigned long long)__popcll(kept));
+#endif
     ph.template end<3>();
     // the kept batches through two LDS buffers: the next one is on its way while this one is tested
     auto first_record = [&](int b) { return beg + (h0 + (uint32_t)b) * kBatch; };
@@ -1050,7 +1073,7 @@ RT_D int queue_len(const Ctl *__restrict__ ctl, int level) {
 // ascending list.
 template <bool COUNT>
 __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
-                                                 Ctl *__restrict__ ctl, int level, PrimaryP prim) {
+                                                 Ctl *__restrict__ ctl, int level, PrimaryP prim, SplitP split) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
@@ -1064,18 +1087,29 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
   Phases ph;
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
-  Tickets tickets((unsigned long long)nrays);
+  // tickets split.from.. are handed out split.ways times each (virtual tickets beyond the real ones)
+  const uint32_t real_tickets = ((uint32_t)nrays + 63u) / 64u;
+  const uint32_t split_from = split.from < real_tickets ? split.from : real_tickets;
+  Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
   for (;;) {
     uint32_t base;
     if (!tickets.take(&ctl->ticket_nearest[level], lane, base)) break;
+    uint32_t own_sub = 0, own_mask = 0, shared = 0;  // shared = index of the ticket among the shared ones
+    if ((base >> 6) >= split_from) {
+      const uint32_t q = (base >> 6) - split_from;
+      own_mask = split.ways - 1u; own_sub = q & own_mask; shared = q / split.ways;
+      base = 64u * (split_from + shared);
+    }
     RT_TICKET(TicketLog tl; tl.begin();)
     const int idx = base + lane;
     Ray ry;
     ry.i = -2;
     if (idx < nrays) { if (prim.on) ry = primary_ray(prim, g, idx, true); else ry = rays[idx]; }
     bool alive = ry.i >= 0;
-    nPixels += __popcll(__ballot(ry.i != -2));
-    nTraced += __popcll(__ballot(alive));
+    if (own_sub == 0u) {  // (a shared ticket's pixels are counted once)
+      nPixels += __popcll(__ballot(ry.i != -2));
+      nTraced += __popcll(__ballot(alive));
+    }
     const f3 o = ld3(ry.o), r = ld3(ry.r);
     f3 pm = mk3(0.0f, 0.0f, 0.0f);  // o x r, |o| and o.r: the ray's side of the filter and of the batch culling
     float onorm = 0.0f, odr = 0.0f;
@@ -1111,6 +1145,9 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
       RT_TICKET(tl.visits++;)
+#ifdef RT_HIST
+      const unsigned long long hist_w0 = nWave, hist_l0 = nLane;
+#endif
       // exit distance of this voxel: a hit only counts if it lies before it (voxelize.c:569,574)
       float best = min3_ref(w.tx + w.dtx, w.ty + w.dty, w.tz + w.dtz);
       int best_id = -1;
@@ -1144,9 +1181,9 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, ph,
+        stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, own_sub, own_mask, ph,
                     [&](f3 c, float delta, f3 hw, float W) {
-                      return wave_any(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
+                      return wave_mask(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
                     [&](int n, int culled) {
                       if (n >= 0) { if (COUNT) { nBatch += n; nCull += culled; } }
@@ -1163,7 +1200,8 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
                     [] { return true; });
       } else if (mode == kLaneMode) {
         proc = is_short;
-        const uint32_t pn = proc ? mycnt : 0u;
+        static_assert(RT_SHORT_LIST <= (1 << kOwnShift), "a short list lies in one ownership unit: share 0 of a shared ticket tests it");
+        const uint32_t pn = proc && own_sub == 0u ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
           if (i < pn) {
@@ -1181,6 +1219,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         int cid = -1;
         uint32_t cpos = 0xffffffffu;
         for (uint32_t t0 = beg; t0 < beg + cnt; t0 += 64) {
+          if ((((t0 - beg) >> kOwnShift) & own_mask) != own_sub) continue;
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
           if (t < beg + cnt) {
@@ -1198,11 +1237,17 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         }
         if (proc) { best = cb; best_id = cid; best_u = cu; best_v = cv; }
       }
+#ifdef RT_HIST
+      if (COUNT) {
+        unsigned long long dl = nLane - hist_l0;
+        for (int off = 32; off > 0; off >>= 1) dl += __shfl_down(dl, off);
+        if (lane == 0) { atomicAdd(&g_mode[0][mode][0], 1ull); atomicAdd(&g_mode[0][mode][1], nWave - hist_w0); atomicAdd(&g_mode[0][mode][2], dl); atomicAdd(&g_mode[0][mode][3], (unsigned long long)__popcll(__ballot(proc))); }
+      }
+#endif
       ph.end<7>();
       if (proc) {
         if (best_id >= 0) {
-          h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v;
-          cell_to_voxel(g, w.cell, h.i, h.j, h.k);
+          h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v;  // (its voxel: w.cell, where the walk now stays)
           alive = false;
         } else {
           alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
@@ -1214,9 +1259,54 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
       }
       ph.end<6>();
     }
-    if (idx < nrays) hits[idx] = h;
+    if (own_mask != 0u) {
+      // A shared ticket.  Every share walked the same cells in the same order and stopped a ray in the first cell in which
+      // one of ITS records gave a hit before the cell's exit distance; the reference stops in the first cell in which any
+      // record does, and takes the smallest (d, index) there: the smallest (steps, d, index) over the shares.  The key's
+      // d is non-negative (+ 0.0f turns -0 into +0), so its bits order like its value.
+      Ray ry2;  // the start voxel again (it was not kept through the walk): steps taken = steps possible at the start - steps left
+      ry2.i = -2;
+      if (idx < nrays) { if (prim.on) ry2 = primary_ray(prim, g, idx, true); else ry2 = rays[idx]; }
+      Walk w2;
+      w2.cell = 0; w2.nx = w2.ny = w2.nz = 0;
+      const int glo[3] = {0, 0, 0}, ghi[3] = {g.nv[0] - 1, g.nv[1] - 1, g.nv[2] - 1};
+      if (ry2.i >= 0) walk_init(g, o, r, ry2.i, ry2.j, ry2.k, glo, ghi, !COUNT, w2);
+      unsigned long long *slot = split.slots + 64ull * shared + lane;
+      unsigned long long key = ~0ull;
+      if (h.tri >= 0) {
+        const int hit_steps = (w2.nx + w2.ny + w2.nz) - (w.nx + w.ny + w.nz);
+        key = ((unsigned long long)hit_steps << 54) | ((unsigned long long)__float_as_uint(h.d + 0.0f) << 22) | (unsigned long long)h.tri;
+      }
+      unsigned long long seen = ~0ull;
+      if (key != ~0ull) seen = atomicMin(slot, key);
+      // (the returned values have arrived: every lane's key is in place before this share reports itself done.  The
+      // shares talk through read-modify-write atomics only, which are performed where all of them see each other, so no
+      // fence is needed: one would write back and invalidate this XCD's whole L2 per ticket)
+      const bool arrived = __ballot(seen == 1ull) != ~0ull;
+      uint32_t before = 0;
+      if (lane == 0 && arrived) before = atomicAdd(&split.done[shared], 1u);
+      before = __builtin_amdgcn_readfirstlane(before);
+      if (before == own_mask) {  // the last share of the ticket writes its hits
+        const unsigned long long k = atomicMin(slot, ~0ull);  // reads the slot where the other shares' atomics put it
+        h.tri = ry2.i >= 0 ? -1 : -2;
+        h.d = h.u = h.v = 0.0f; h.i = h.j = h.k = 0;
+        if (k != ~0ull) {
+          const int id = (int)(k & 0x3fffffull);
+          float d, u, v;
+          (void)exact_test(g, id, o, r, d, u, v);  // the same arithmetic on the same inputs as in the share that found it
+          h.tri = id; h.d = __uint_as_float((uint32_t)(k >> 22)); h.u = u; h.v = v;
+          for (int q = (int)(k >> 54); q > 0; q--) (void)walk_step(g, r, w2);
+          cell_to_voxel(g, w2.cell, h.i, h.j, h.k);
+        }
+        if (idx < nrays) hits[idx] = h;
+        nHits += __popcll(__ballot(h.tri >= 0));
+      }
+    } else {
+      if (h.tri >= 0) cell_to_voxel(g, w.cell, h.i, h.j, h.k);
+      if (idx < nrays) hits[idx] = h;
+      nHits += __popcll(__ballot(h.tri >= 0));
+    }
     RT_TICKET(ph.end<0>(); if (level == 0) tl.end(0, base, lane, ph); busy += __builtin_amdgcn_s_memtime() - tl.t0;)
-    nHits += __popcll(__ballot(h.tri >= 0));
   }
   RT_TICKET(if (level == 0) TicketLog::life(0, lane, busy, born);)
   ph.end<0>();
@@ -1421,7 +1511,7 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 template <bool COUNT>
 __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const SOrigin *__restrict__ sorg,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
-                                                long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base) {
+                                                long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base, SplitP split) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
@@ -1435,10 +1525,20 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   Phases ph;
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
-  Tickets tickets((unsigned long long)total);
+  // tickets split.from.. are handed out split.ways times each (only in scenes without transparent triangles: a
+  // transparency product has an order, a blocker has none)
+  const uint32_t real_tickets = (uint32_t)((total + 63) / 64);
+  const uint32_t split_from = split.from < real_tickets ? split.from : real_tickets;
+  Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
   for (;;) {
     uint32_t base;
     if (!tickets.take(&ctl->ticket_shadow[level], lane, base)) break;
+    uint32_t own_sub = 0, own_mask = 0, shared = 0;
+    if ((base >> 6) >= split_from) {
+      const uint32_t q = (base >> 6) - split_from;
+      own_mask = split.ways - 1u; own_sub = q & own_mask; shared = q / split.ways;
+      base = 64u * (split_from + shared);
+    }
     RT_TICKET(TicketLog tl; tl.begin();)
     const long long item = (long long)base + lane;
     bool alive = false;
@@ -1505,6 +1605,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       const int mode = pick_mode(__popcll(__ballot(in_group)), cnt, __popcll(__ballot(is_short)));
       if (COUNT) nVisit++;
       RT_TICKET(tl.visits++;)
+#ifdef RT_HIST
+      const unsigned long long hist_w0 = nWave, hist_l0 = nLane;
+#endif
       bool proc;  // this lane's current cell is fully tested (or the ray blocked) after this step
       // One triangle for one shadow ray: 0 = no effect, 2 = accepted hit of a transparent triangle, 3 = opaque
       // blocker inside (1e-5, dmax); the filter decides what it can prove, tri_test the rest (:700-711).
@@ -1540,9 +1643,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, ph,
+          stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
-                        return wave_any(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
+                        return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },
                       [&](int n, int culled) {
                         if (n >= 0) { if (COUNT) { nBatch += n; nCull += culled; } }
@@ -1560,7 +1663,11 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
                           if (verdict == 2) {
                             ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
                           } else if (verdict == 3) {
+#ifdef RT_HIST
+                            result = -(float)(rec_id(R) + 2); kc = -INFINITY;  // (diagnostic build: which triangle blocked the ray)
+#else
                             result = -1.0f; kc = -INFINITY;
+#endif
                           }
                           go = __ballot(kc != -INFINITY) != 0;
                         });
@@ -1569,7 +1676,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         alive = alive & (result >= 0.0f);
       } else if (mode == kLaneMode) {
         proc = is_short;
-        uint32_t pn = proc ? mycnt : 0u;
+        uint32_t pn = proc && own_sub == 0u ? mycnt : 0u;  // (a short list lies in one ownership unit: share 0 tests it)
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
           if (i < pn) {
@@ -1590,6 +1697,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float cts = lane_bcast(ts, leader);
         bool blocked = false;
         for (uint32_t t0 = beg; t0 < beg + cnt && !blocked; t0 += 64) {
+          if ((((t0 - beg) >> kOwnShift) & own_mask) != own_sub) continue;
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
           int verdict = 0;
@@ -1606,6 +1714,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
           if (blocked) { result = -1.0f; alive = false; } else ts = cts;
         }
       }
+#ifdef RT_HIST
+      if (COUNT) {
+        unsigned long long dl = nLane - hist_l0;
+        for (int off = 32; off > 0; off >>= 1) dl += __shfl_down(dl, off);
+        const unsigned long long np = (unsigned long long)__popcll(__ballot(proc));
+        if (lane == 0) { atomicAdd(&g_mode[1][mode][0], 1ull); atomicAdd(&g_mode[1][mode][1], nWave - hist_w0); atomicAdd(&g_mode[1][mode][2], dl); atomicAdd(&g_mode[1][mode][3], np); }
+      }
+#endif
       ph.end<7>();
       if (proc && alive) {
         alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
@@ -1616,8 +1732,32 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       }
       ph.end<6>();
     }
-    // slot-major: the 64 lanes of a ticket are consecutive hits of one slot, so the store is one 256-byte line
-    if (have_result) ts_out[(long long)slot * ts_stride + (node_base + nidx)] = result < 0.0f ? -1.0f : ts;
+    if (own_mask != 0u) {
+      // A shared ticket (no transparent triangle in the scene, so ts stays 1): a ray is in shadow if any share found a
+      // blocker.  The shares OR their blocked rays into the ticket's mask; the one that finishes last writes the results.
+      unsigned long long *mask = split.slots + shared;
+      const unsigned long long mine = __ballot(result < 0.0f);
+      unsigned long long seen = 0;
+      if (lane == 0) seen = atomicOr(mask, mine);
+      const bool arrived = __ballot(seen == 1ull) != ~0ull;  // (the atomic has been performed before this share reports itself done)
+      uint32_t before = 0;
+      if (lane == 0 && arrived) before = atomicAdd(&split.done[shared], 1u);
+      before = __builtin_amdgcn_readfirstlane(before);
+      if (before == own_mask) {
+        unsigned long long all = 0;
+        if (lane == 0) all = atomicOr(mask, 0ull);  // reads the mask where the other shares' atomics put it
+        all = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(all >> 32)) << 32) |
+              (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)all);  // (readfirstlane gives a signed int)
+        if (have_result) ts_out[(long long)slot * ts_stride + (node_base + nidx)] = ((all >> lane) & 1ull) ? -1.0f : ts;
+      }
+    } else if (have_result) {
+      // slot-major: the 64 lanes of a ticket are consecutive hits of one slot, so the store is one 256-byte line
+#ifdef RT_HIST
+      ts_out[(long long)slot * ts_stride + (node_base + nidx)] = result < 0.0f ? result : ts;  // (diagnostic build: the blocker stays visible)
+#else
+      ts_out[(long long)slot * ts_stride + (node_base + nidx)] = result < 0.0f ? -1.0f : ts;
+#endif
+    }
     RT_TICKET(ph.end<0>(); if (level == 0) tl.end(1, base, lane, ph); busy += __builtin_amdgcn_s_memtime() - tl.t0;)
   }
   RT_TICKET(if (level == 0) TicketLog::life(1, lane, busy, born);)

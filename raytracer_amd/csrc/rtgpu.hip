@@ -111,6 +111,11 @@ struct rtgpu_ctx {
   Hit *d_hits = nullptr;  // sized for the largest level
   Node *d_nodes = nullptr;
   SOrigin *d_sorg = nullptr;  // hit point + triangle of every node: what the shadow walk reads
+  // tickets shared by several wavefronts (SplitP): merge slots and arrival counters of the nearest and the shadow walk
+  unsigned long long *d_split_keys = nullptr, *d_split_masks = nullptr;
+  uint32_t *d_split_done_n = nullptr, *d_split_done_s = nullptr;
+  int opt_split_kernels = 3;  // option "split_kernels": bit 0 nearest walk, bit 1 shadow walk (diagnostic)
+  int opt_split = 0;  // option "split": 0 never, 1 as the queue length suggests, 2 / 4: every ticket, that many ways
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
   PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
   int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
@@ -252,6 +257,12 @@ int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
   if ((rc = give((void **)&c->d_partial, sizeof(float) * ((tiles * kTilePixels + 255) / 256 * 6)))) return rc;  // colour range per block of level 0
   const size_t nrank = c->npl > 0 ? total : 1;
   if ((rc = give((void **)&c->d_rank, sizeof(int32_t) * nrank)) || (rc = give((void **)&c->d_size, sizeof(int32_t) * nrank))) return rc;
+  // shared tickets exist only in scenes without secondary rays (one level, no transparent triangle)
+  const size_t st = c->fan == 0 ? tiles : 0, ss = st * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1);
+  if ((rc = give((void **)&c->d_split_keys, sizeof(unsigned long long) * (st * kTilePixels + 1))) ||
+      (rc = give((void **)&c->d_split_masks, sizeof(unsigned long long) * (ss + 1))) ||
+      (rc = give((void **)&c->d_split_done_n, sizeof(uint32_t) * (st + 1))) || (rc = give((void **)&c->d_split_done_s, sizeof(uint32_t) * (ss + 1))))
+    return rc;
   return RTGPU_OK;
 }
 
@@ -289,6 +300,7 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
 // The chunk queues of a context, as a value: rtgpu_render_static puts the carved ones in and the context's own back.
 struct QueueSet {
   size_t chunk_tiles_cap, cap[kMaxLevels], base[kMaxLevels], total_nodes;
+  unsigned long long *d_split_keys, *d_split_masks; uint32_t *d_split_done_n, *d_split_done_s;
   Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; SOrigin *d_sorg; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size;
 };
 QueueSet take_queues(rtgpu_ctx *c) {
@@ -297,6 +309,8 @@ QueueSet take_queues(rtgpu_ctx *c) {
   for (int L = 0; L < kMaxLevels; L++) { q.cap[L] = c->cap[L]; q.base[L] = c->base[L]; q.d_rays[L] = c->d_rays[L]; c->d_rays[L] = nullptr; }
   q.d_hits = c->d_hits; q.d_nodes = c->d_nodes; q.d_sorg = c->d_sorg; q.d_colors = c->d_colors; q.d_ts = c->d_ts; q.d_partial = c->d_partial;
   q.d_rank = c->d_rank; q.d_size = c->d_size;
+  q.d_split_keys = c->d_split_keys; q.d_split_masks = c->d_split_masks; q.d_split_done_n = c->d_split_done_n; q.d_split_done_s = c->d_split_done_s;
+  c->d_split_keys = c->d_split_masks = nullptr; c->d_split_done_n = c->d_split_done_s = nullptr;
   c->d_hits = nullptr; c->d_nodes = nullptr; c->d_sorg = nullptr; c->d_colors = c->d_ts = c->d_partial = nullptr; c->d_rank = c->d_size = nullptr;
   return q;
 }
@@ -305,6 +319,7 @@ void put_queues(rtgpu_ctx *c, const QueueSet &q) {
   for (int L = 0; L < kMaxLevels; L++) { c->cap[L] = q.cap[L]; c->base[L] = q.base[L]; c->d_rays[L] = q.d_rays[L]; }
   c->d_hits = q.d_hits; c->d_nodes = q.d_nodes; c->d_sorg = q.d_sorg; c->d_colors = q.d_colors; c->d_ts = q.d_ts; c->d_partial = q.d_partial;
   c->d_rank = q.d_rank; c->d_size = q.d_size;
+  c->d_split_keys = q.d_split_keys; c->d_split_masks = q.d_split_masks; c->d_split_done_n = q.d_split_done_n; c->d_split_done_s = q.d_split_done_s;
 }
 
 // The glibc rand() stream from seed 1, at least `need` values, on the device.
@@ -411,7 +426,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
-  dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_ctl); dev_free(&c->d_totals);
+  dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_split_keys); dev_free(&c->d_split_masks); dev_free(&c->d_split_done_n); dev_free(&c->d_split_done_s); dev_free(&c->d_ctl); dev_free(&c->d_totals);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -438,6 +453,8 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
+  else if (!strcmp(name, "split_kernels")) c->opt_split_kernels = (int)value;
+  else if (!strcmp(name, "split")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, RTGPU_E_INVALID_PARAM, "split: 0, 1, 2 or 4"); c->opt_split = (int)value; }
   else if (!strcmp(name, "queue_margin")) { if (value < 1 || value > 100000) return fail(c, RTGPU_E_INVALID_PARAM, "queue_margin out of range"); c->queue_margin_permille = (int)value; }
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
@@ -684,6 +701,24 @@ unsigned node_blocks(size_t cap, int level) {
   return (unsigned)(level == 0 || b < 4096 ? (b ? b : 1) : 4096);
 }
 
+// Which tickets of a walk kernel are shared by several wavefronts.  A ticket is 64 rays and costs what its rays meet: on
+// temple the heaviest takes 15 times the average, and a walk kernel is not over before its slowest ticket is.  With
+// few tickets per wavefront (a small share of a frame: one rank of eight) every ticket is shared two or four ways;
+// with many, only the last eighth of the queue, which the wavefronts take one ticket at a time at the end of the walk.
+// Only in scenes without secondary rays (no transparent triangle: a blocker has no order, a transparency product
+// has), not while counting (the statistics are per ray), and within the widths of the merge key.
+SplitP plan_split(const rtgpu_ctx *c, long long tickets, int waves, unsigned long long *slots, uint32_t *done) {
+  SplitP s{0xffffffffu, 1u, slots, done};
+  const GridP &g = c->grid;
+  if (c->fan != 0 || c->opt_count || c->opt_split == 0 || tickets <= 0 || c->nt >= (1 << 22) || g.nv[0] + g.nv[1] + g.nv[2] >= 1000) return s;
+  if (c->opt_split >= 2) { s.from = 0; s.ways = (uint32_t)c->opt_split; return s; }
+  const long long per_wave = tickets / (waves > 0 ? waves : 1);
+  if (per_wave < 4) { s.from = 0; s.ways = 4; }
+  else if (per_wave < 12) { s.from = 0; s.ways = 2; }
+  else { s.from = (uint32_t)(tickets - tickets / 8); s.ways = 2; }
+  return s;
+}
+
 // One chunk of tiles, first half: primary rays, then nearest-hit walk and hit kernel level by level
 // (raytrace.c:170-204); with planar lights also the number of shaded hits in every node's subtree.
 int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
@@ -701,12 +736,22 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   }
   for (int L = 0; L < c->levels; L++) {
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+    SplitP split{0xffffffffu, 1u, c->d_split_keys, c->d_split_done_n};
+    if (L == 0) {
+      const long long tickets = ((long long)n0 + 63) / 64;
+      if (c->opt_split_kernels & 1) split = plan_split(c, tickets, pgrid * 4, c->d_split_keys, c->d_split_done_n);
+      if (split.ways > 1) {
+        const size_t shared = (size_t)(tickets - split.from);
+        HIPCHK(c, hipMemsetAsync(c->d_split_keys, 0xff, sizeof(unsigned long long) * 64 * shared, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_split_done_n, 0, sizeof(uint32_t) * shared, c->stream));
+      }
+    }
     {
       Span sp(c, W_NEAREST);
       if (c->opt_count)
-        KLAUNCH(c, k_nearest<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
+        KLAUNCH(c, k_nearest<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split);
       else
-        KLAUNCH(c, k_nearest<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued);
+        KLAUNCH(c, k_nearest<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split);
     }
     {
       Span sp(c, W_HIT);
@@ -755,12 +800,22 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * RT_WAVES) + 3) / 4);
   if (c->shade.nslots > 0) {
     for (int L = 0; L < c->levels; L++) {
+      SplitP split{0xffffffffu, 1u, c->d_split_masks, c->d_split_done_s};
+      if (L == 0) {
+        const long long tickets = ((long long)n0 * c->shade.nslots + 63) / 64;
+        if (c->opt_split_kernels & 2) split = plan_split(c, tickets, pgrid * 4, c->d_split_masks, c->d_split_done_s);
+        if (split.ways > 1) {
+          const size_t shared = (size_t)(tickets - split.from);
+          HIPCHK(c, hipMemsetAsync(c->d_split_masks, 0, sizeof(unsigned long long) * shared, c->stream));
+          HIPCHK(c, hipMemsetAsync(c->d_split_done_s, 0, sizeof(uint32_t) * shared, c->stream));
+        }
+      }
       Span sp(c, W_SHADOW);
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       if (c->opt_count)
-        KLAUNCH(c, k_shadow<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L]);
+        KLAUNCH(c, k_shadow<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split);
       else
-        KLAUNCH(c, k_shadow<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L]);
+        KLAUNCH(c, k_shadow<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split);
     }
   }
   PrimaryP queued = c->prim;
@@ -1062,10 +1117,20 @@ int rtgpu_phase_cycles(rtgpu_ctx *c, int64_t out[16], int reset) {
 }
 
 #ifdef RT_HIST
+// the shadow results of the last chunk, slot-major (diagnostic build: a blocked ray holds -(blocking triangle + 2))
+int rtgpu_debug_ts(rtgpu_ctx *c, float *out, long long nodes, int nslots) {
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int s = 0; s < nslots; s++)
+    HIPCHK(c, hipMemcpy(out + (size_t)s * nodes, c->d_ts + (size_t)s * c->total_nodes, sizeof(float) * (size_t)nodes, hipMemcpyDeviceToHost));
+  return RTGPU_OK;
+}
 int rtgpu_debug_hist(rtgpu_ctx *c, unsigned long long *out) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(unsigned long long) * 36));
+  HIPCHK(c, hipMemcpyFromSymbol(out + 36, HIP_SYMBOL(g_cand), sizeof(unsigned long long) * 8));
+  HIPCHK(c, hipMemcpyFromSymbol(out + 44, HIP_SYMBOL(g_mode), sizeof(unsigned long long) * 24));
   return RTGPU_OK;
 }
 #endif

@@ -16,8 +16,9 @@ h = int(sys.argv[3]) if len(sys.argv) > 3 else 2160
 sc = rt.Scene(os.path.join(ROOT, SCENES[scene]), width=w, height=h)
 r = rt.Renderer(0)
 r.upload(sc)
+r.set_option("count", 1)  # the per-mode statistics come from the counting variants of the kernels
 r.frame_begin(); r.render_host()
-out = (C.c_ulonglong * 36)()
+out = (C.c_ulonglong * 68)()
 L = rt.gpu_lib()
 L.rtgpu_debug_hist.argtypes = [C.c_void_p, C.c_void_p]
 L.rtgpu_debug_hist(r._h, out)
@@ -28,3 +29,12 @@ for k, name in enumerate(("nearest", "shadow")):
     print(name, "batches tested", tb, "pairs", tp)
     for i in range(9):
         print("  %d records passed by some lane: %5.1f %% of batches, %5.1f %% of pairs, %5.1f pairs per batch" % (i, 100.0 * b[i] / tb, 100.0 * p[i] / tp, p[i] / max(b[i], 1)))
+    c = v[36 + 4 * k:40 + 4 * k]
+    print("  headers looked at %d, passed the bundle test %d (%.1f %%), kept by the ray-by-ray test %d (%.1f %% of headers, %.1f %% of candidates)"
+          % (c[0], c[1], 100.0 * c[1] / max(c[0], 1), c[2], 100.0 * c[2] / max(c[0], 1), 100.0 * c[2] / max(c[1], 1)))
+    print("  rays that may meet the box of a kept batch: %.2f on average" % (c[3] / max(c[2], 1)))
+    m = v[44 + 12 * k:56 + 12 * k]
+    for i, mode in enumerate(("cell", "lane", "ray")):
+        vis, wv, ln, rays = m[4 * i:4 * i + 4]
+        print("  %s mode: %d visits (%.1f rays per visit), %d wave-level record tests (%.1f per visit), lane use %.3f"
+              % (mode, vis, rays / max(vis, 1), wv, wv / max(vis, 1), ln / max(64 * wv, 1)))

@@ -18,6 +18,9 @@ scene = rt.Scene(os.path.join(ROOT, SCENES[name]), width=w, height=h)
 r = rt.Renderer(0, timing=1)
 if len(sys.argv) > 5:
     r.set_option("waves_per_cu", int(sys.argv[5]))
+for kv in os.environ.get("RT_OPTIONS", "").split(","):  # e.g. RT_OPTIONS=split=0,pipeline=0
+    if "=" in kv:
+        r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 r.upload(scene)
 dev = torch.device("cuda:0")
 r.set_stream(torch.cuda.current_stream(dev))
