@@ -122,6 +122,11 @@ struct rtgpu_ctx {
   Ctl *d_ctl = nullptr;
   unsigned char *scratch = nullptr;  // this device's copy of the static scratch array (rtgpu_render_static)
   unsigned long long *d_totals = nullptr;  // [kStatCount + kMaxLevels + 1]
+  // device buffers of the host-array conveniences (rtgpu_render_host, rtgpu_tonemap_host): kept and grown, not allocated per call
+  float *h_rgb_t = nullptr, *h_rgb = nullptr, *h_mm = nullptr;
+  int32_t *h_ids_t = nullptr, *h_ids = nullptr;
+  uint32_t *h_rgba = nullptr;
+  size_t h_cap_tiles = 0, h_cap_px = 0, h_cap_tone = 0;
   // timing
   std::vector<TimedSpan> spans;
   rtgpu_timings timings = {};
@@ -426,6 +431,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
+  dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba);
   dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_split_keys); dev_free(&c->d_split_masks); dev_free(&c->d_split_done_n); dev_free(&c->d_split_done_s); dev_free(&c->d_ctl); dev_free(&c->d_totals);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1165,41 +1171,50 @@ int rtgpu_render_host(rtgpu_ctx *c, float *rgb, int32_t *ids, float *minmax) {
   if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t nt = rtgpu_tile_count(c, 0, 1), npx = (int64_t)c->cam.sw * c->cam.sh;
-  float *d_rgb_t = nullptr, *d_rgb = nullptr, *d_mm = nullptr;
-  int32_t *d_ids_t = nullptr, *d_ids = nullptr;
   int rc = RTGPU_OK;
-  if ((rc = dev_alloc(c, &d_rgb_t, (size_t)nt * kTilePixels * 3)) || (rc = dev_alloc(c, &d_ids_t, (size_t)nt * kTilePixels)) ||
-      (rc = dev_alloc(c, &d_rgb, (size_t)npx * 3)) || (rc = dev_alloc(c, &d_ids, (size_t)npx)) || (rc = dev_alloc(c, &d_mm, 6))) {
-  } else if ((rc = rtgpu_render(c, 0, 1, d_rgb_t, d_ids_t, d_mm)) || (rc = rtgpu_untile(c, d_rgb_t, 1, 12, d_rgb)) ||
-             (rc = rtgpu_untile(c, d_ids_t, 1, 4, d_ids))) {
-  } else {
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess && rgb) e = hipMemcpy(rgb, d_rgb, sizeof(float) * 3 * npx, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && ids) e = hipMemcpy(ids, d_ids, sizeof(int32_t) * npx, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && minmax) e = hipMemcpy(minmax, d_mm, sizeof(float) * 6, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(c, RTGPU_E_NO_DEVICE, std::string("render_host: ") + hipGetErrorString(e));
+  // the tile-major and row-major device copies are kept from call to call and only grow
+  if ((size_t)nt > c->h_cap_tiles) {
+    c->h_cap_tiles = 0;
+    if ((rc = dev_alloc(c, &c->h_rgb_t, (size_t)nt * kTilePixels * 3)) || (rc = dev_alloc(c, &c->h_ids_t, (size_t)nt * kTilePixels))) return rc;
+    c->h_cap_tiles = (size_t)nt;
   }
-  dev_free(&d_rgb_t); dev_free(&d_ids_t); dev_free(&d_rgb); dev_free(&d_ids); dev_free(&d_mm);
-  return rc;
+  if ((size_t)npx > c->h_cap_px) {
+    c->h_cap_px = 0;
+    if ((rc = dev_alloc(c, &c->h_rgb, (size_t)npx * 3)) || (rc = dev_alloc(c, &c->h_ids, (size_t)npx))) return rc;
+    c->h_cap_px = (size_t)npx;
+  }
+  if (!c->h_mm && (rc = dev_alloc(c, &c->h_mm, 6))) return rc;
+  if ((rc = rtgpu_render(c, 0, 1, c->h_rgb_t, c->h_ids_t, c->h_mm)) || (rc = rtgpu_untile(c, c->h_rgb_t, 1, 12, c->h_rgb)) ||
+      (rc = rtgpu_untile(c, c->h_ids_t, 1, 4, c->h_ids)))
+    return rc;
+  if (rgb) HIPCHK(c, hipMemcpyAsync(rgb, c->h_rgb, sizeof(float) * 3 * npx, hipMemcpyDeviceToHost, c->stream));
+  if (ids) HIPCHK(c, hipMemcpyAsync(ids, c->h_ids, sizeof(int32_t) * npx, hipMemcpyDeviceToHost, c->stream));
+  if (minmax) HIPCHK(c, hipMemcpyAsync(minmax, c->h_mm, sizeof(float) * 6, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RTGPU_OK;
 }
 
 int rtgpu_tonemap_host(rtgpu_ctx *c, const float *rgb, int64_t n, const float *minmax, float gamma, uint32_t *rgba) {
   if (!c || !rgb || !minmax || !rgba || n < 0) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));
-  float *d_rgb = nullptr, *d_mm = nullptr;
-  uint32_t *d_out = nullptr;
   int rc = RTGPU_OK;
-  if ((rc = dev_alloc(c, &d_rgb, (size_t)n * 3)) || (rc = dev_alloc(c, &d_mm, 6)) || (rc = dev_alloc(c, &d_out, (size_t)n))) {
-  } else {
-    hipError_t e = hipMemcpy(d_rgb, rgb, sizeof(float) * 3 * n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_mm, minmax, sizeof(float) * 6, hipMemcpyHostToDevice);
-    if (e == hipSuccess) rc = rtgpu_tonemap(c, d_rgb, n, d_mm, gamma, d_out);
-    if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess && !rc) e = hipMemcpy(rgba, d_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(c, RTGPU_E_NO_DEVICE, std::string("tonemap_host: ") + hipGetErrorString(e));
+  if ((size_t)n > c->h_cap_px) {  // (shares the row-major colour buffer of rtgpu_render_host)
+    c->h_cap_px = 0;
+    if ((rc = dev_alloc(c, &c->h_rgb, (size_t)n * 3)) || (rc = dev_alloc(c, &c->h_ids, (size_t)n))) return rc;
+    c->h_cap_px = (size_t)n;
   }
-  dev_free(&d_rgb); dev_free(&d_mm); dev_free(&d_out);
-  return rc;
+  if ((size_t)n > c->h_cap_tone) {
+    c->h_cap_tone = 0;
+    if ((rc = dev_alloc(c, &c->h_rgba, (size_t)n))) return rc;
+    c->h_cap_tone = (size_t)n;
+  }
+  if (!c->h_mm && (rc = dev_alloc(c, &c->h_mm, 6))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_rgb, rgb, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_mm, minmax, sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
+  if ((rc = rtgpu_tonemap(c, c->h_rgb, n, c->h_mm, gamma, c->h_rgba))) return rc;
+  HIPCHK(c, hipMemcpyAsync(rgba, c->h_rgba, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RTGPU_OK;
 }
 
 int rtgpu_grid_download(rtgpu_ctx *c, int32_t *cell_start, int32_t *refs) {
