@@ -183,8 +183,8 @@ int rtgpu_render(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_i
  * the pixel loop (hits, shaded-hit nodes, secondary rays, shadow results, partial colour ranges) live in a static device
  * array of rtgpu_static_scratch_bytes() = 64 MiB that every GPU the library runs on holds until the process ends; the
  * call makes no hipMalloc, hipFree or other allocating call (per-kernel "timing" is off for it: it would create events).
- * This rank's whole share of the image is traced as one chunk, so its queues have to fit the array (temple: 124 bytes per
- * pixel, about 540 000 pixels; ulica, 64 lights and depth 5: about 11 KB per pixel); a larger share, a scene with planar
+ * This rank's whole share of the image is traced as one chunk, so its queues have to fit the array (temple: 145 bytes per
+ * pixel, about 460 000 pixels; ulica, 64 lights and depth 5, worst-case queues: about 13 KB per pixel); a larger share, a scene with planar
  * lights (their random-number table is sized at run time) or a device index above 63 is refused with
  * RTGPU_E_UNSUPPORTED and a message that says which, before anything is enqueued.  All contexts of one GPU share that
  * GPU's array and it keeps the last call's contents (nothing in it has to be cleared: every entry is written before
