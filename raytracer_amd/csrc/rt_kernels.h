@@ -221,12 +221,12 @@ RT_D bool box_separated(const BoxRay &b, f3 r, f3 hw, float W, float delta, floa
   return (__builtin_fabsf(b.ex) > sx) | (__builtin_fabsf(b.ey) > sy) | (__builtin_fabsf(b.ez) > sz) | (b.tc + hr < 0.0f) | (b.tc - hr > tmax);
 }
 RT_D bool box_test_bundle(f3 c, float radius, f3 h, bool transparent, float inv_cos, float ga, float gb, float slack, const Bundle &bu,
-                          bool transparent_counts_anywhere, float &w_ray, float &delta) {
+                          bool transparent_counts_anywhere, float &w_ray, float &delta, float &tv) {
   const BoxRay b = box_ray(c, bu.axis, bu.m, bu.odr);
   const float d2 = __builtin_fmaf(b.ex, b.ex, __builtin_fmaf(b.ey, b.ey, b.ez * b.ez));
   const float on5 = 0.00001f * bu.onorm;
-  float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(b.tc, b.tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
-  tv = __builtin_fmaf(bu.ro, 1.001f, tv);
+  tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(b.tc, b.tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
+  tv = __builtin_fmaf(bu.ro, 1.001f, tv);  // >= |o - v| for every ray origin o of the bundle and every vertex v of the batch
   delta = __builtin_fmaf(0.00001f, tv, on5 + on5);
   w_ray = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, delta) + slack;
   const float W = w_ray + __builtin_fmaf(bu.rho, tv + (h.x + h.y + h.z) + (w_ray + w_ray), bu.ro) * 1.001f;
@@ -329,6 +329,42 @@ RT_D void wait_staged() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Field access of a record in LDS or in memory (float index: n 0-2, k1 3, ik 4-6, q 7-9, id 10, k2 11,
+// ij 12-14, p 15-17, an 18, kt 19).  The first slab needs n, ik, q: two 16-byte reads and one 8-byte read.
+struct RecA { f3 n, ac, q; };
+RT_D RecA rec_a(const float *R) {
+  const v4f x = *reinterpret_cast<const v4f *>(R);
+  const v4f y = *reinterpret_cast<const v4f *>(R + 4);
+  const v2f z = *reinterpret_cast<const v2f *>(R + 8);
+  RecA a; a.n = mk3(x.x, x.y, x.z); a.ac = mk3(y.x, y.y, y.z); a.q = mk3(y.w, z.x, z.y);
+  return a;
+}
+
+// The first slab of the filter (pl_stage1) for a whole bundle at once: can ANY ray of the bundle pass it for this record?
+// false only if surely none can, and then tri_test rejects the triangle for every ray of the bundle.
+// For one ray, with the exact values on the float inputs marked *: det* = r.N, tp* = (o - a).(r x ac) (a: the vertex
+// the filter labels i, ac its longest edge), x1* = 2 tp* - det*, and tri_test accepts only if
+// |x1*| <= |det*| (1 + 7 eps) + kc, kc = k1 |o| + k2 (rt_math.h: the bound proven for the computed values, 71 eps L (|o| + A)
+// + 28 eps L^2, plus what the computed values are off by, 14.4 eps L (|o| + A) + 4.1 eps L^2, stays below k1 |o| + k2 = 144
+// eps L (|o| + A) + 56 eps L^2).  A ray of the bundle has r = axis + dr, |dr| <= rho, o = o_L + do, |do| <= ro, so against
+// the leader's values  |det* - det_L*| <= rho |N|,  |tp* - tp_L*| = |do.(r x ac) + (o_L - a).(dr x ac)| <= (1.000001 ro + tv rho) |ac|
+// (tv >= |o_L - a| from box_test_bundle), hence |x1* - x1_L*| <= D = 2 (1.000001 ro + tv rho) |ac| + rho |N|.  The leader's computed
+// x1', det' are within kc_L / 2 and kc_L / 4 of x1_L*, det_L*.  So no ray of the bundle can satisfy the acceptance condition if
+//     |x1'| > (|det'| + rho |N|) 1.00001 + D + 2 kc_max,      kc_max = k1 onorm_max + k2 (+ slack: infinite when the filter is off)
+// (2 kc_max covers kc/2 + kc/4 (1 + 7 eps) + kc of the ray itself); D and the norms are rounded up by 0.1 %.  A NaN compares false.
+RT_D bool bundle_slab_pass(f3 N, f3 ac, f3 Q, float kc_max, float tv, const Bundle &bu) {
+  const float det = __builtin_fmaf(bu.axis.x, N.x, __builtin_fmaf(bu.axis.y, N.y, bu.axis.z * N.z));
+  const float rq = __builtin_fmaf(bu.axis.x, Q.x, __builtin_fmaf(bu.axis.y, Q.y, bu.axis.z * Q.z));
+  const float tp = __builtin_fmaf(bu.m.x, ac.x, __builtin_fmaf(bu.m.y, ac.y, __builtin_fmaf(bu.m.z, ac.z, -rq)));
+  const float x1 = __builtin_fmaf(2.0f, tp, -det);
+  const float nN = __builtin_amdgcn_sqrtf(__builtin_fmaf(N.x, N.x, __builtin_fmaf(N.y, N.y, N.z * N.z))) * 1.001f;
+  const float nac = __builtin_amdgcn_sqrtf(__builtin_fmaf(ac.x, ac.x, __builtin_fmaf(ac.y, ac.y, ac.z * ac.z))) * 1.001f;
+  const float rn = bu.rho * nN;
+  const float D = __builtin_fmaf(2.0f * nac, __builtin_fmaf(tv, bu.rho, 1.000001f * bu.ro), rn) * 1.001f;
+  const float T = __builtin_fmaf(__builtin_fabsf(det) + rn, 1.00001f, D + (kc_max + kc_max));
+  return !(__builtin_fabsf(x1) > T);
+}
+
 // Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
 // batch the bundle's leader ray, widened to contain every ray of the bundle, is tested against the batch's box first (one
 // lane per batch); for the batches that remain cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides
@@ -372,12 +408,13 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     if (lane < nh) {
       float *H = hs + lane * kHdrFloats;
       const v4f hc = *reinterpret_cast<const v4f *>(H), hh = *reinterpret_cast<const v4f *>(H + 4), k = *reinterpret_cast<const v4f *>(H + 8);
-      float w_ray, delta;
+      float w_ray, delta, tv;
       maybe = box_test_bundle(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle,
-                              transparent_counts_anywhere, w_ray, delta);
+                              transparent_counts_anywhere, w_ray, delta, tv);
       if (maybe) {
         H[3] = k.y < 0.0f ? -delta : delta;
         *reinterpret_cast<v4f *>(H + 4) = v4f{hh.x + w_ray, hh.y + w_ray, hh.z + w_ray, w_ray};
+        H[10] = tv;  // (ga, gb have done their work: the slot keeps the bundle's distance bound for the record-level test)
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -388,7 +425,12 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
 #endif
     // ray by ray: which of the candidates can any ray of the wavefront meet
     unsigned long long kept = 0;
+#ifdef RT_NO_RAY_CULL
+    kept = candidates;
+    for (unsigned long long cm = 0; cm != 0; cm &= cm - 1) {
+#else
     for (unsigned long long cm = candidates; cm != 0; cm &= cm - 1) {
+#endif
       const int b = __ffsll(cm) - 1;
       const v4f hc = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats);      // c, -+delta
       const v4f hw = *reinterpret_cast<const v4f *>(hs + b * kHdrFloats + 4);  // h + W, W
@@ -404,6 +446,39 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
 #ifdef RT_HIST
     if (lane == 0) atomicAdd(&g_cand[transparent_counts_anywhere ? 1 : 0][2], (unsigned long long)__popcll(kept));
 #endif
+    // Record by record, for the bundle: the kept batches are numbered in list order (their numbers go through LDS), lane
+    // 8 i + j takes record j of kept batch p0 + i and asks whether any ray of the bundle can pass the record's first slab
+    // (bundle_slab_pass).  The batch's header keeps one bit per surviving record (in the slot of gb, which has done its
+    // work); a kept batch without a surviving record is not even staged.
+    static_assert(kBatch == 8 && kHdrChunk <= 32, "the record-level bundle test maps 8 batches of 8 records onto the 64 lanes");
+    {
+      const uint32_t kept_all = (uint32_t)kept;
+      const int nkept = __popc(kept_all);
+      int *number = reinterpret_cast<int *>(rs);  // (the record buffers are not in use yet)
+      if (lane < kHdrChunk && ((kept_all >> lane) & 1u)) number[__popc(kept_all & ((1u << lane) - 1u))] = lane;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+      for (int p0 = 0; p0 < nkept; p0 += 8) {
+        const int q = p0 + (lane >> 3);
+        bool pass = false;
+        int b = 0;
+        if (q < nkept) {
+          b = number[q];
+          const uint32_t pos = beg + (h0 + (uint32_t)b) * kBatch + (uint32_t)(lane & 7);
+          if (pos < beg + cnt) {
+            const float *R = reinterpret_cast<const float *>(recs + pos);
+            const RecA A = rec_a(R);
+            const float *H = hs + b * kHdrFloats;
+            const float kc_max = __builtin_fmaf(H[8], bundle.onorm, __builtin_fabsf(H[9])) + g.slack;
+            pass = bundle_slab_pass(A.n, A.ac, A.q, kc_max, H[10], bundle);
+          }
+        }
+        const unsigned long long m = __ballot(pass);
+        if (q < nkept && (lane & 7) == 0) hs[b * kHdrFloats + 11] = __uint_as_float((uint32_t)(m >> (lane & 56)) & 0xffu);
+      }
+      __builtin_amdgcn_wave_barrier();
+      kept = __ballot(lane < kHdrChunk && ((kept_all >> lane) & 1u) && __float_as_uint(hs[lane * kHdrFloats + 11]) != 0u);
+    }
     ph.template end<3>();
     // the kept batches through two LDS buffers: the next one is on its way while this one is tested
     auto first_record = [&](int b) { return beg + (h0 + (uint32_t)b) * kBatch; };
@@ -417,7 +492,6 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       const int b = __ffsll(kept) - 1;
       kept &= kept - 1;
       const uint32_t c0 = first_record(b);
-      const int n = records_of(c0);
       const float *rb = rs + buf * (kBatch * kRecFloats);
       wait_staged();
       if (kept != 0) {
@@ -428,34 +502,20 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       ph.template end<4, true>();
       const v2f k = *reinterpret_cast<const v2f *>(hs + b * kHdrFloats + 8);  // k1, -+k2
       batch(k.x, __builtin_fabsf(k.y));
-      tally(-2, n);  // n records are about to be tested
+      uint32_t todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(hs[b * kHdrFloats + 11]));  // the batch's records that some ray of the bundle may pass
+      tally(-2, __popc(todo));
 #ifdef RT_HIST
       {
         int hrec = 0, hpairs = 0;
-        for (int q = 0; q < n; q++) { const unsigned long long mm = __ballot(pass1(rb + q * kRecFloats)); hrec += mm != 0; hpairs += __popcll(mm); }
-        if (lane == 0) { atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][0][hrec], 1ull); atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][1][hrec], (unsigned long long)hpairs); }
+        for (uint32_t q = todo; q != 0; q &= q - 1) { const unsigned long long mm = __ballot(pass1(rb + (__ffs(q) - 1) * kRecFloats)); hrec += mm != 0; hpairs += __popcll(mm); }
+        if (lane == 0) { atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][0][hrec], 1ull); atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][1][hrec], (unsigned long long)hpairs);
+                         atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][1][0], (unsigned long long)__popc(todo)); }  // (no pairs in a batch without a passing record: the slot counts the records left by the bundle's slab test)
       }
 #endif
-      int j = 0;
-      for (; j + RT_UNROLL <= n; j += RT_UNROLL) {
-        unsigned long long m[RT_UNROLL], any = 0;
-#pragma unroll
-        for (int q = 0; q < RT_UNROLL; q++) { m[q] = __ballot(pass1(rb + (j + q) * kRecFloats)); any |= m[q]; }
-        asm volatile("" : "+s"(any));
-        if (any != 0) {
-          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into per-lane ones
-#pragma unroll
-          for (int q = 0; q < RT_UNROLL; q++) {
-            if (m[q] != 0) {
-              f(rb + (j + q) * kRecFloats, c0 + (uint32_t)(j + q));
-              if (!more()) { wait_staged(); ph.template end<5>(); return; }
-            }
-          }
-        }
-      }
-      for (; j < n; ++j) {
+      for (; todo != 0; todo &= todo - 1) {
+        const int j = __ffs(todo) - 1;
         if (wave_any(pass1(rb + j * kRecFloats))) {
-          asm volatile("; some lane passed the first slab");
+          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into per-lane ones
           f(rb + j * kRecFloats, c0 + (uint32_t)j);
           if (!more()) { wait_staged(); ph.template end<5>(); return; }
         }
@@ -469,17 +529,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
 }
 constexpr int kSliceFloats = kHdrChunk * kHdrFloats + 2 * kBatch * kRecFloats;  // LDS floats per wavefront
 
-// Field access of a record in LDS or in memory (float index: n 0-2, k1 3, ik 4-6, q 7-9, id 10, k2 11,
-// ij 12-14, p 15-17, an 18, kt 19).  The first slab needs n, ik, q: two 16-byte reads and one 8-byte read.
-struct RecA { f3 n, ac, q; };
 struct RecB { f3 ab, p; float an, kt; };
-RT_D RecA rec_a(const float *R) {
-  const v4f x = *reinterpret_cast<const v4f *>(R);
-  const v4f y = *reinterpret_cast<const v4f *>(R + 4);
-  const v2f z = *reinterpret_cast<const v2f *>(R + 8);
-  RecA a; a.n = mk3(x.x, x.y, x.z); a.ac = mk3(y.x, y.y, y.z); a.q = mk3(y.w, z.x, z.y);
-  return a;
-}
 RT_D RecB rec_b(const float *R) {
   const v4f x = *reinterpret_cast<const v4f *>(R + 12);
   const v4f y = *reinterpret_cast<const v4f *>(R + 16);

@@ -157,7 +157,8 @@ def _box_separated(e, r, hw, W, delta, tmax):
 
 def bundle_box_may_hit(H, inv_cos, axis, ml, odl, onorm, tmax, ro, rho):
     """box_test_bundle of rt_kernels.h, operation by operation in float32: the leader's ray (axis, ml, odl) for every
-    ray within ro, rho of it.  Returns (may hit, W for a single ray of the bundle, delta)."""
+    ray within ro, rho of it.  Returns (may hit, W for a single ray of the bundle, delta, tv = the bundle's bound of the
+    distance from a ray origin to a vertex of the batch)."""
     c, h = H["c"], H["h"]
     k = lambda x: np.full_like(onorm, F(x))
     with np.errstate(all="ignore"):
@@ -171,7 +172,24 @@ def bundle_box_may_hit(H, inv_cos, axis, ml, odl, onorm, tmax, ro, rho):
         w_ray = fma(fma(H["gb"], tv, H["ga"]), inv_cos, delta)
         W = w_ray + fma(rho, tv + (h[:, 0] + h[:, 1] + h[:, 2]) + (w_ray + w_ray), ro) * F(1.001)
         out = _box_separated(e, axis, (h[:, 0] + W, h[:, 1] + W, h[:, 2] + W), W, delta, tmax)
-    return ~out, w_ray, delta
+    return ~out, w_ray, delta, tv
+
+
+def bundle_slab_pass(T, kc_max, tv, axis, ml, ro, rho):
+    """bundle_slab_pass of rt_kernels.h, operation by operation in float32: may any ray of the bundle pass the record's first slab?"""
+    N, ac, Q = T["N"], T["ac"], T["Q"]
+    k = lambda x: np.full_like(tv, F(x))
+    with np.errstate(all="ignore"):
+        det = fma(axis[:, 0], N[:, 0], fma(axis[:, 1], N[:, 1], axis[:, 2] * N[:, 2]))
+        rq = fma(axis[:, 0], Q[:, 0], fma(axis[:, 1], Q[:, 1], axis[:, 2] * Q[:, 2]))
+        tp = fma(ml[:, 0], ac[:, 0], fma(ml[:, 1], ac[:, 1], fma(ml[:, 2], ac[:, 2], -rq)))
+        x1 = fma(k(2), tp, -det)
+        nN = np.sqrt(fma(N[:, 0], N[:, 0], fma(N[:, 1], N[:, 1], N[:, 2] * N[:, 2]))) * F(1.001)
+        nac = np.sqrt(fma(ac[:, 0], ac[:, 0], fma(ac[:, 1], ac[:, 1], ac[:, 2] * ac[:, 2]))) * F(1.001)
+        rn = rho * nN
+        D = fma(F(2.0) * nac, fma(tv, rho, F(1.000001) * ro), rn) * F(1.001)
+        Tt = fma(np.abs(det) + rn, k(1.00001), D + (kc_max + kc_max))
+        return ~(np.abs(x1) > Tt)
 
 
 def ray_box_may_hit(H, w_ray, delta, r, m, odr, tmax):
@@ -185,7 +203,7 @@ def ray_box_may_hit(H, w_ray, delta, r, m, odr, tmax):
 def box_may_hit(H, inv_cos, r, m, odr, onorm, tmax):
     """Both levels for a bundle of this one ray (ro = 0, rho = 1e-7, as make_bundle gives)."""
     zero, tiny = np.zeros_like(onorm), np.full_like(onorm, F(1e-7))
-    b, w_ray, delta = bundle_box_may_hit(H, inv_cos, r, m, odr, onorm, tmax, zero, tiny)
+    b, w_ray, delta, _ = bundle_box_may_hit(H, inv_cos, r, m, odr, onorm, tmax, zero, tiny)
     return b & ray_box_may_hit(H, w_ray, delta, r, m, odr, tmax)
 
 
@@ -277,6 +295,7 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
     #    culled for an accepted hit; the bundle is the ray and a second direction up to 2 degrees away
     H = batch_header(T)
     other = (r + (rng.standard_normal((n, 3)) * 10.0 ** rng.uniform(-6, -1.5, (n, 1))).astype(F)).astype(F)
+    slab_stats = []
     for axis in (r, other):
         dlt = r - axis
         rho = (np.sqrt(dot32(dlt, dlt)) * F(1.001) + F(1e-7)).astype(F)
@@ -293,13 +312,19 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
         for bound, which, what in ((np.full(n, np.inf, F), acc, "an accepted hit"), (best, acc & (d < best), "a nearer hit"),
                                    (dmax, blocker, "a blocker")):
             tb = np.maximum(bound, bound[::-1])  # the bundle's bound is the largest of its rays'
-            may, w_ray, delta = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, tb, ro, rho)
+            may, w_ray, delta, tv = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, tb, ro, rho)
             assert may[which].all(), "bundle test culled " + what
             # ... and with the bundle's W and delta this ray's own test must not cull it either
             assert ray_box_may_hit(H, w_ray, delta, r, m, odr, bound)[which].all(), "ray test with the bundle's margins culled " + what
+        # the record-level test of the bundle: a triangle that this ray of the bundle hits is never dropped for the bundle
+        kc_max = fma(T["k1"], onb, np.abs(T["k2"]))
+        slab = bundle_slab_pass(T, kc_max, tv, axis, ml, ro, rho)
+        assert slab[acc].all(), "the bundle's first-slab test dropped a triangle one of its rays hits"
+        slab_stats.append((slab[~acc].mean(), float(np.median(rho))))
     fuzz = batch_cos(H, r, np.full(n, F(1e-7), F))
     # the filter is not vacuous: it rejects most misses and proves most clear hits
     if aim is aim_anywhere:
+        assert slab_stats[0][0] < 0.9, "the bundle's first-slab test keeps everything: vacuous"
         assert (~p1 | ~p2)[~acc].mean() > 0.5
         assert (~box_may_hit(H, fuzz, r, m, odr, onorm, np.full(n, np.inf, F)))[~acc].mean() > 0.2
     if aim is aim_inside and scale == 1.0 and offset == 0.0:  # (small triangles far from the origin leave little to prove)

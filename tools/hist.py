@@ -25,8 +25,9 @@ L.rtgpu_debug_hist(r._h, out)
 v = list(out)
 for k, name in enumerate(("nearest", "shadow")):
     b, p = v[18 * k:18 * k + 9], v[18 * k + 9:18 * k + 18]
+    left, p[0] = p[0], 0
     tb, tp = sum(b) or 1, sum(p) or 1
-    print(name, "batches tested", tb, "pairs", tp)
+    print(name, "batches tested", tb, "pairs", tp, "records left by the bundle's slab test: %.2f per batch" % (left / tb))
     for i in range(9):
         print("  %d records passed by some lane: %5.1f %% of batches, %5.1f %% of pairs, %5.1f pairs per batch" % (i, 100.0 * b[i] / tb, 100.0 * p[i] / tp, p[i] / max(b[i], 1)))
     c = v[36 + 4 * k:40 + 4 * k]
