@@ -9,9 +9,6 @@
 #include "rt_math.h"
 #include "rt_texture.h"
 
-#ifndef RT_UNROLL
-#define RT_UNROLL 4
-#endif
 #ifndef RT_WAVES
 #define RT_WAVES 6  // waves per SIMD the shadow walk is compiled for (80 VGPRs; with 8 and 64 VGPRs it spills and runs 6 % slower)
 #endif
@@ -24,13 +21,10 @@ namespace rt {
 RT_D int lane_id() { return threadIdx.x & 63; }
 RT_D unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
-// Streams the packed triangle list [beg, end) of one cell through every lane of the wavefront.
-// The wavefront copies the list to its private LDS slice in batches of kBatch records with coalesced
-// 16-byte direct-to-LDS loads, then every lane reads the same record back (LDS broadcast).  batch(k1, k2) is
-// called once per batch with the batch's filter constants, f(record, index) once per record, in list
-// order, with wave-uniform arguments; more() is a wave-uniform predicate evaluated after each record
-// (false = stop early).  LDS operations of one wavefront execute in issue order, so no barrier is needed
-// between the copy and the reads, nor before the next batch overwrites the slice.
+// A cell's list reaches the lanes of a wavefront through the wavefront's private LDS slice: batches of kBatch records
+// are copied there with coalesced 16-byte direct-to-LDS loads, then every lane reads the same record back (LDS
+// broadcast).  LDS operations of one wavefront execute in issue order, so no barrier is needed between the copy and
+// the reads, nor before the next batch overwrites the slice (stream_cell).
 using v4f = float __attribute__((ext_vector_type(4)));
 using v2f = float __attribute__((ext_vector_type(2)));
 constexpr int kRecVecs = kRecFloats / 4;
@@ -340,29 +334,42 @@ RT_D RecA rec_a(const float *R) {
   return a;
 }
 
-// The first slab of the filter (pl_stage1) for a whole bundle at once: can ANY ray of the bundle pass it for this record?
-// false only if surely none can, and then tri_test rejects the triangle for every ray of the bundle.
-// For one ray, with the exact values on the float inputs marked *: det* = r.N, tp* = (o - a).(r x ac) (a: the vertex
-// the filter labels i, ac its longest edge), x1* = 2 tp* - det*, and tri_test accepts only if
-// |x1*| <= |det*| (1 + 7 eps) + kc, kc = k1 |o| + k2 (rt_math.h: the bound proven for the computed values, 71 eps L (|o| + A)
-// + 28 eps L^2, plus what the computed values are off by, 14.4 eps L (|o| + A) + 4.1 eps L^2, stays below k1 |o| + k2 = 144
+struct RecB { f3 ab, p; float an, kt; };
+RT_D RecB rec_b(const float *R) {
+  const v4f x = *reinterpret_cast<const v4f *>(R + 12);
+  const v4f y = *reinterpret_cast<const v4f *>(R + 16);
+  RecB b; b.ab = mk3(x.x, x.y, x.z); b.p = mk3(x.w, y.x, y.y); b.an = y.z; b.kt = y.w;
+  return b;
+}
+
+// The three slabs of the filter (pl_stage1, pl_stage2) for a whole bundle at once: can ANY ray of the bundle pass them for
+// this record?  false only if surely none can, and then tri_test rejects the triangle for every ray of the bundle.
+// For one ray, with the exact values on the float inputs marked *: det* = r.N, tp* = (o - i).(r x ik), vp* = r.((o - i) x ij),
+// X1* = 2 tp* - det*, X2* = 2 vp* - det*, X3* = 2 (tp* + vp*) - det*, and tri_test accepts only if for each of them
+// |X*| <= |det*| (1 + 7 eps) + kc, kc = k1 |o| + k2 (rt_math.h: the bound proven for the computed values, 71 eps L (|o| + A)
+// + 28 eps L^2, plus what the computed values are off by, at most 31 eps L (|o| + A) + 5 eps L^2, stays below k1 |o| + k2 = 144
 // eps L (|o| + A) + 56 eps L^2).  A ray of the bundle has r = axis + dr, |dr| <= rho, o = o_L + do, |do| <= ro, so against
-// the leader's values  |det* - det_L*| <= rho |N|,  |tp* - tp_L*| = |do.(r x ac) + (o_L - a).(dr x ac)| <= (1.000001 ro + tv rho) |ac|
-// (tv >= |o_L - a| from box_test_bundle), hence |x1* - x1_L*| <= D = 2 (1.000001 ro + tv rho) |ac| + rho |N|.  The leader's computed
-// x1', det' are within kc_L / 2 and kc_L / 4 of x1_L*, det_L*.  So no ray of the bundle can satisfy the acceptance condition if
-//     |x1'| > (|det'| + rho |N|) 1.00001 + D + 2 kc_max,      kc_max = k1 onorm_max + k2 (+ slack: infinite when the filter is off)
-// (2 kc_max covers kc/2 + kc/4 (1 + 7 eps) + kc of the ray itself); D and the norms are rounded up by 0.1 %.  A NaN compares false.
-RT_D bool bundle_slab_pass(f3 N, f3 ac, f3 Q, float kc_max, float tv, const Bundle &bu) {
-  const float det = __builtin_fmaf(bu.axis.x, N.x, __builtin_fmaf(bu.axis.y, N.y, bu.axis.z * N.z));
-  const float rq = __builtin_fmaf(bu.axis.x, Q.x, __builtin_fmaf(bu.axis.y, Q.y, bu.axis.z * Q.z));
-  const float tp = __builtin_fmaf(bu.m.x, ac.x, __builtin_fmaf(bu.m.y, ac.y, __builtin_fmaf(bu.m.z, ac.z, -rq)));
+// the leader's values  |det* - det_L*| <= rho |N|,  |tp* - tp_L*| = |do.(r x ik) + (o_L - i).(dr x ik)| <= E = (1.000001 ro + tv rho) L
+// (tv >= |o_L - i| from box_test_bundle; L = |ik|, the longest edge), the same for vp with |ij| <= L, hence
+// |X1* - X1_L*|, |X2* - X2_L*| <= 2 E + rho |N| and |X3* - X3_L*| <= 4 E + rho |N|.  The leader's computed X', det' are
+// within kc_L / 4 of X_L*, det_L*.  So no ray of the bundle can satisfy the acceptance conditions if for one of the three
+//     |X'| > (|det'| + rho |N|) 1.00001 + D + 2 kc_max,      kc_max = k1 onorm_max + k2 (+ slack: infinite when the filter is off)
+// (2 kc_max covers kc / 4 + kc / 4 (1 + 7 eps) + kc of the ray itself); E and the norms are rounded up by 0.1 %.  A NaN compares false.
+RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float tv, const Bundle &bu) {
+  const float det = __builtin_fmaf(bu.axis.x, A.n.x, __builtin_fmaf(bu.axis.y, A.n.y, bu.axis.z * A.n.z));
+  const float rq = __builtin_fmaf(bu.axis.x, A.q.x, __builtin_fmaf(bu.axis.y, A.q.y, bu.axis.z * A.q.z));
+  const float tp = __builtin_fmaf(bu.m.x, A.ac.x, __builtin_fmaf(bu.m.y, A.ac.y, __builtin_fmaf(bu.m.z, A.ac.z, -rq)));
+  const float rp = __builtin_fmaf(bu.axis.x, P.x, __builtin_fmaf(bu.axis.y, P.y, bu.axis.z * P.z));
+  const float nv = __builtin_fmaf(bu.m.x, ab.x, __builtin_fmaf(bu.m.y, ab.y, __builtin_fmaf(bu.m.z, ab.z, rp)));  // -vp
   const float x1 = __builtin_fmaf(2.0f, tp, -det);
-  const float nN = __builtin_amdgcn_sqrtf(__builtin_fmaf(N.x, N.x, __builtin_fmaf(N.y, N.y, N.z * N.z))) * 1.001f;
-  const float nac = __builtin_amdgcn_sqrtf(__builtin_fmaf(ac.x, ac.x, __builtin_fmaf(ac.y, ac.y, ac.z * ac.z))) * 1.001f;
+  const float x2 = __builtin_fmaf(-2.0f, nv, -det);
+  const float x3 = __builtin_fmaf(2.0f, tp - nv, -det);
+  const float nN = __builtin_amdgcn_sqrtf(__builtin_fmaf(A.n.x, A.n.x, __builtin_fmaf(A.n.y, A.n.y, A.n.z * A.n.z))) * 1.001f;
+  const float L = __builtin_amdgcn_sqrtf(__builtin_fmaf(A.ac.x, A.ac.x, __builtin_fmaf(A.ac.y, A.ac.y, A.ac.z * A.ac.z))) * 1.002f;  // (|ij| <= |ik| up to rounding)
   const float rn = bu.rho * nN;
-  const float D = __builtin_fmaf(2.0f * nac, __builtin_fmaf(tv, bu.rho, 1.000001f * bu.ro), rn) * 1.001f;
-  const float T = __builtin_fmaf(__builtin_fabsf(det) + rn, 1.00001f, D + (kc_max + kc_max));
-  return !(__builtin_fabsf(x1) > T);
+  const float E2 = (2.0f * L) * __builtin_fmaf(tv, bu.rho, 1.000001f * bu.ro) * 1.001f;  // 2 E
+  const float T = __builtin_fmaf(__builtin_fabsf(det) + rn, 1.00001f, rn + (kc_max + kc_max));
+  return !((__builtin_fmaxf(__builtin_fabsf(x1), __builtin_fabsf(x2)) > T + E2) | (__builtin_fabsf(x3) > T + (E2 + E2)));
 }
 
 // Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
@@ -370,11 +377,10 @@ RT_D bool bundle_slab_pass(f3 N, f3 ac, f3 Q, float kc_max, float tv, const Bund
 // lane per batch); for the batches that remain cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides
 // ray by ray, for the whole wavefront, whether any of its rays can meet the box; only then are the batch's records staged and tested:
 //   batch(k1, k2)      once per surviving batch, with the batch's filter constants
-//   pass1(record)      the side-effect-free first stage of the test (true = this lane cannot reject the
-//                      triangle yet), evaluated for RT_UNROLL records at a time; only if it holds in some
-//                      lane for some of them does the wavefront leave the straight-line path and run
-//   f(record, index)   the full test on those records, in list order, checking
-//   more()             (wave-uniform) after each: false = stop.
+//   f(record, index)   the test of one record the bundle's record-level test could not drop, for all lanes; true (wave-uniform)
+//                      if some lane passed the first slab and the rest of the test ran, and only then
+//   more()             (wave-uniform) is asked: false = stop.
+//   pass1(record)      the side-effect-free first slab on its own, for the statistics of diagnostic builds.
 // own_sub, own_mask: for a ticket shared by own_mask + 1 wavefronts, only the header chunks (256 records) whose index
 // & own_mask equals own_sub are looked at (0, 0: all of them).
 template <typename C, typename T, typename B, typename P, typename F, typename G>
@@ -448,7 +454,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
 #endif
     // Record by record, for the bundle: the kept batches are numbered in list order (their numbers go through LDS), lane
     // 8 i + j takes record j of kept batch p0 + i and asks whether any ray of the bundle can pass the record's first slab
-    // (bundle_slab_pass).  The batch's header keeps one bit per surviving record (in the slot of gb, which has done its
+    // (bundle_slabs_pass).  The batch's header keeps one bit per surviving record (in the slot of gb, which has done its
     // work); a kept batch without a surviving record is not even staged.
     static_assert(kBatch == 8 && kHdrChunk <= 32, "the record-level bundle test maps 8 batches of 8 records onto the 64 lanes");
     {
@@ -468,9 +474,10 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
           if (pos < beg + cnt) {
             const float *R = reinterpret_cast<const float *>(recs + pos);
             const RecA A = rec_a(R);
+            const RecB Rb = rec_b(R);
             const float *H = hs + b * kHdrFloats;
             const float kc_max = __builtin_fmaf(H[8], bundle.onorm, __builtin_fabsf(H[9])) + g.slack;
-            pass = bundle_slab_pass(A.n, A.ac, A.q, kc_max, H[10], bundle);
+            pass = bundle_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[10], bundle);
           }
         }
         const unsigned long long m = __ballot(pass);
@@ -514,11 +521,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
 #endif
       for (; todo != 0; todo &= todo - 1) {
         const int j = __ffs(todo) - 1;
-        if (wave_any(pass1(rb + j * kRecFloats))) {
-          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into per-lane ones
-          f(rb + j * kRecFloats, c0 + (uint32_t)j);
-          if (!more()) { wait_staged(); ph.template end<5>(); return; }
-        }
+        if (f(rb + j * kRecFloats, c0 + (uint32_t)j) && !more()) { wait_staged(); ph.template end<5>(); return; }
       }
       __builtin_amdgcn_wave_barrier();
       ph.template end<5, true>();
@@ -529,13 +532,6 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
 }
 constexpr int kSliceFloats = kHdrChunk * kHdrFloats + 2 * kBatch * kRecFloats;  // LDS floats per wavefront
 
-struct RecB { f3 ab, p; float an, kt; };
-RT_D RecB rec_b(const float *R) {
-  const v4f x = *reinterpret_cast<const v4f *>(R + 12);
-  const v4f y = *reinterpret_cast<const v4f *>(R + 16);
-  RecB b; b.ab = mk3(x.x, x.y, x.z); b.p = mk3(x.w, y.x, y.y); b.an = y.z; b.kt = y.w;
-  return b;
-}
 RT_D int rec_id(const float *R) { return __float_as_int(R[10]); }
 // The exact test of a triangle the filter could not decide: i, ij, ik by index.
 RT_D bool exact_test(const GridP &g, int id, f3 o, f3 r, float &d, float &u, float &v, bool *full = nullptr) {
@@ -1224,7 +1220,9 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
             if (exact_test(g, id, to, tr, d, u, v, COUNT ? &full : nullptr) && id != cur && (d < b || (d == b && id < bid))) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
             if (COUNT && full) nFull++;
           }
+          return true;
         }
+        return false;
       };
       uint32_t nopos = 0;
       if (mode == kCellMode) {
@@ -1241,12 +1239,14 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
                     },
                     [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                     [&](const float *R) {
-                      if (COUNT) { nWave++; if (proc) nLane++; }
                       const RecA A = rec_a(R);
                       PlTest t;
                       return pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
                     },
-                    [&](const float *R, uint32_t) { test(R, o, r, pm, kc, ry.current, best, best_id, best_u, best_v, 0u, nopos); },
+                    [&](const float *R, uint32_t) {
+                      if (COUNT) { nWave++; if (proc) nLane++; }
+                      return test(R, o, r, pm, kc, ry.current, best, best_id, best_u, best_v, 0u, nopos);
+                    },
                     [] { return true; });
       } else if (mode == kLaneMode) {
         proc = is_short;
@@ -1685,7 +1685,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
             }
           }
           react(verdict, kt);
+          return true;
         }
+        return false;
       };
       if (mode == kCellMode) {
         proc = in_group;
@@ -1703,13 +1705,13 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
                       },
                       [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                       [&](const float *R) {
-                        if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
                         const RecA A = rec_a(R);
                         PlTest t;
                         return pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
                       },
                       [&](const float *R, uint32_t) {
-                        test(R, a, r, pm, kc, current, dmax, [&](int verdict, float kt) {
+                        if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
+                        return test(R, a, r, pm, kc, current, dmax, [&](int verdict, float kt) {
                           if (verdict == 2) {
                             ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)
                           } else if (verdict == 3) {

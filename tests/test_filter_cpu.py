@@ -175,21 +175,25 @@ def bundle_box_may_hit(H, inv_cos, axis, ml, odl, onorm, tmax, ro, rho):
     return ~out, w_ray, delta, tv
 
 
-def bundle_slab_pass(T, kc_max, tv, axis, ml, ro, rho):
-    """bundle_slab_pass of rt_kernels.h, operation by operation in float32: may any ray of the bundle pass the record's first slab?"""
-    N, ac, Q = T["N"], T["ac"], T["Q"]
+def bundle_slabs_pass(T, kc_max, tv, axis, ml, ro, rho):
+    """bundle_slabs_pass of rt_kernels.h, operation by operation in float32: may any ray of the bundle pass the record's three slabs?"""
+    N, ac, Q, ab, P = T["N"], T["ac"], T["Q"], T["ab"], T["P"]
     k = lambda x: np.full_like(tv, F(x))
     with np.errstate(all="ignore"):
         det = fma(axis[:, 0], N[:, 0], fma(axis[:, 1], N[:, 1], axis[:, 2] * N[:, 2]))
         rq = fma(axis[:, 0], Q[:, 0], fma(axis[:, 1], Q[:, 1], axis[:, 2] * Q[:, 2]))
         tp = fma(ml[:, 0], ac[:, 0], fma(ml[:, 1], ac[:, 1], fma(ml[:, 2], ac[:, 2], -rq)))
+        rp = fma(axis[:, 0], P[:, 0], fma(axis[:, 1], P[:, 1], axis[:, 2] * P[:, 2]))
+        nv = fma(ml[:, 0], ab[:, 0], fma(ml[:, 1], ab[:, 1], fma(ml[:, 2], ab[:, 2], rp)))
         x1 = fma(k(2), tp, -det)
+        x2 = fma(k(-2), nv, -det)
+        x3 = fma(k(2), tp - nv, -det)
         nN = np.sqrt(fma(N[:, 0], N[:, 0], fma(N[:, 1], N[:, 1], N[:, 2] * N[:, 2]))) * F(1.001)
-        nac = np.sqrt(fma(ac[:, 0], ac[:, 0], fma(ac[:, 1], ac[:, 1], ac[:, 2] * ac[:, 2]))) * F(1.001)
+        L = np.sqrt(fma(ac[:, 0], ac[:, 0], fma(ac[:, 1], ac[:, 1], ac[:, 2] * ac[:, 2]))) * F(1.002)
         rn = rho * nN
-        D = fma(F(2.0) * nac, fma(tv, rho, F(1.000001) * ro), rn) * F(1.001)
-        Tt = fma(np.abs(det) + rn, k(1.00001), D + (kc_max + kc_max))
-        return ~(np.abs(x1) > Tt)
+        E2 = (F(2.0) * L) * fma(tv, rho, F(1.000001) * ro) * F(1.001)
+        Tt = fma(np.abs(det) + rn, k(1.00001), rn + (kc_max + kc_max))
+        return ~((np.maximum(np.abs(x1), np.abs(x2)) > Tt + E2) | (np.abs(x3) > Tt + (E2 + E2)))
 
 
 def ray_box_may_hit(H, w_ray, delta, r, m, odr, tmax):
@@ -318,13 +322,13 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
             assert ray_box_may_hit(H, w_ray, delta, r, m, odr, bound)[which].all(), "ray test with the bundle's margins culled " + what
         # the record-level test of the bundle: a triangle that this ray of the bundle hits is never dropped for the bundle
         kc_max = fma(T["k1"], onb, np.abs(T["k2"]))
-        slab = bundle_slab_pass(T, kc_max, tv, axis, ml, ro, rho)
-        assert slab[acc].all(), "the bundle's first-slab test dropped a triangle one of its rays hits"
+        slab = bundle_slabs_pass(T, kc_max, tv, axis, ml, ro, rho)
+        assert slab[acc].all(), "the bundle's slab test dropped a triangle one of its rays hits"
         slab_stats.append((slab[~acc].mean(), float(np.median(rho))))
     fuzz = batch_cos(H, r, np.full(n, F(1e-7), F))
     # the filter is not vacuous: it rejects most misses and proves most clear hits
     if aim is aim_anywhere:
-        assert slab_stats[0][0] < 0.9, "the bundle's first-slab test keeps everything: vacuous"
+        assert slab_stats[0][0] < 0.9, "the bundle's slab test keeps everything: vacuous"
         assert (~p1 | ~p2)[~acc].mean() > 0.5
         assert (~box_may_hit(H, fuzz, r, m, odr, onorm, np.full(n, np.inf, F)))[~acc].mean() > 0.2
     if aim is aim_inside and scale == 1.0 and offset == 0.0:  # (small triangles far from the origin leave little to prove)
