@@ -147,6 +147,9 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * what the scene's chunks produce, which costs one host synchronisation per chunk, and a chunk whose queues turn out too small
  * is rendered again with worst-case queues; 0: always worst case, 31 nodes per pixel at depth 5, no synchronisation),
  * "queue_margin" (default 1500: queues are planned for the largest ratio seen so far x 1.5; in permille),
+ * "record_test" (default -1: by the scene; 1 / 0: the walk kernels test the records of a batch against the whole bundle of a
+ * wavefront's rays before they stage the batch, or do not: same image either way; it pays where bundles are narrow against
+ * the triangles, and -1 switches it on unless half of the scene's triangles or more are transparent),
  * "filter" (default 1; 0 switches off the conservative triangle filter and the batch culling of the
  * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */
 int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);

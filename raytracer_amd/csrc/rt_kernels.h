@@ -9,6 +9,9 @@
 #include "rt_math.h"
 #include "rt_texture.h"
 
+#ifndef RT_DENSE
+#define RT_DENSE 7  // a batch with at least this many records left by the bundle's test has all its records tested in fixed groups of four
+#endif
 #ifndef RT_WAVES
 #define RT_WAVES 6  // waves per SIMD the shadow walk is compiled for (80 VGPRs; with 8 and 64 VGPRs it spills and runs 6 % slower)
 #endif
@@ -377,13 +380,16 @@ RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float tv, 
 // lane per batch); for the batches that remain cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides
 // ray by ray, for the whole wavefront, whether any of its rays can meet the box; only then are the batch's records staged and tested:
 //   batch(k1, k2)      once per surviving batch, with the batch's filter constants
-//   f(record, index)   the test of one record the bundle's record-level test could not drop, for all lanes; true (wave-uniform)
-//                      if some lane passed the first slab and the rest of the test ran, and only then
+//   f(record, index, first)  the test of one record, for all lanes (first: pass1 has not seen the record, for the
+//                      statistics); true (wave-uniform) if some lane passed the first slab and the rest of the test ran, and only then
 //   more()             (wave-uniform) is asked: false = stop.
-//   pass1(record)      the side-effect-free first slab on its own, for the statistics of diagnostic builds.
+//   pass1(record)      the side-effect-free first slab on its own: batches in which most records survive run it for four
+//                      records at a time before f; also for the statistics of diagnostic builds.
+// RECTEST: with the record-level test of the bundle (bundle_slabs_pass) between the ray-by-ray test of the boxes and the
+// staging; without it every record of a kept batch is tested.  It pays where bundles are narrow against the triangles.
 // own_sub, own_mask: for a ticket shared by own_mask + 1 wavefronts, only the header chunks (256 records) whose index
 // & own_mask equals own_sub are looked at (0, 0: all of them).
-template <typename C, typename T, typename B, typename P, typename F, typename G>
+template <bool RECTEST, typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
                       bool transparent_counts_anywhere, uint32_t own_sub, uint32_t own_mask, Phases &ph, C &&cull, T &&tally, B &&batch,
                       P &&pass1, F &&f, G &&more) {
@@ -457,7 +463,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     // (bundle_slabs_pass).  The batch's header keeps one bit per surviving record (in the slot of gb, which has done its
     // work); a kept batch without a surviving record is not even staged.
     static_assert(kBatch == 8 && kHdrChunk <= 32, "the record-level bundle test maps 8 batches of 8 records onto the 64 lanes");
-    {
+    if (RECTEST) {
       const uint32_t kept_all = (uint32_t)kept;
       const int nkept = __popc(kept_all);
       int *number = reinterpret_cast<int *>(rs);  // (the record buffers are not in use yet)
@@ -509,7 +515,8 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       ph.template end<4, true>();
       const v2f k = *reinterpret_cast<const v2f *>(hs + b * kHdrFloats + 8);  // k1, -+k2
       batch(k.x, __builtin_fabsf(k.y));
-      uint32_t todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(hs[b * kHdrFloats + 11]));  // the batch's records that some ray of the bundle may pass
+      // the batch's records that some ray of the bundle may pass
+      uint32_t todo = RECTEST ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(hs[b * kHdrFloats + 11])) : (1u << records_of(c0)) - 1u;
       tally(-2, __popc(todo));
 #ifdef RT_HIST
       {
@@ -519,9 +526,28 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
                          atomicAdd(&g_hist[transparent_counts_anywhere ? 1 : 0][1][0], (unsigned long long)__popc(todo)); }  // (no pairs in a batch without a passing record: the slot counts the records left by the bundle's slab test)
       }
 #endif
+      if (!RECTEST || __popc(todo) >= RT_DENSE) {
+        // most records survive: all of them, four at a time through the first slab in straight-line code (LDS offsets
+        // are immediates, the reads and FMA chains of four records overlap), then the whole test for those some lane passed
+        const int n = records_of(c0);
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {
+          unsigned long long m[4], any = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) { m[q] = __ballot(pass1(rb + (j + q) * kRecFloats)); any |= m[q]; }
+          asm volatile("" : "+s"(any));  // (an opaque scalar: the branch stays a scalar branch)
+          if (any != 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              if (m[q] != 0 && f(rb + (j + q) * kRecFloats, c0 + (uint32_t)(j + q), false) && !more()) { wait_staged(); ph.template end<5>(); return; }
+            }
+          }
+        }
+        todo &= ~0u << j;  // a partial batch's last records: one by one
+      }
       for (; todo != 0; todo &= todo - 1) {
         const int j = __ffs(todo) - 1;
-        if (f(rb + j * kRecFloats, c0 + (uint32_t)j) && !more()) { wait_staged(); ph.template end<5>(); return; }
+        if (f(rb + j * kRecFloats, c0 + (uint32_t)j, true) && !more()) { wait_staged(); ph.template end<5>(); return; }
       }
       __builtin_amdgcn_wave_barrier();
       ph.template end<5, true>();
@@ -1117,7 +1143,7 @@ RT_D int queue_len(const Ctl *__restrict__ ctl, int level) {
 // non-empty cell.  Every listed triangle of a visited cell is accounted for (tested, or proven irrelevant by
 // the culling), and of equal distances the smallest triangle index wins, as in the reference's scan of its
 // ascending list.
-template <bool COUNT>
+template <bool COUNT, bool RECTEST>
 __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
                                                  Ctl *__restrict__ ctl, int level, PrimaryP prim, SplitP split) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
@@ -1229,7 +1255,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, own_sub, own_mask, ph,
+        stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, own_sub, own_mask, ph,
                     [&](f3 c, float delta, f3 hw, float W) {
                       return wave_mask(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
@@ -1239,12 +1265,13 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
                     },
                     [&](float k1, float k2) { kc = proc ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                     [&](const float *R) {
+                      if (COUNT) { nWave++; if (proc) nLane++; }
                       const RecA A = rec_a(R);
                       PlTest t;
                       return pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
                     },
-                    [&](const float *R, uint32_t) {
-                      if (COUNT) { nWave++; if (proc) nLane++; }
+                    [&](const float *R, uint32_t, bool first) {
+                      if (COUNT && first) { nWave++; if (proc) nLane++; }
                       return test(R, o, r, pm, kc, ry.current, best, best_id, best_u, best_v, 0u, nopos);
                     },
                     [] { return true; });
@@ -1558,7 +1585,7 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 // transparency product ts (>= 0) if the light is visible, -1 if the point is in shadow, stored slot-major too
 // (ts_out[slot * ts_stride + node]: one full line per ticket).
 // The reference's per-triangle shadow cache (voxelize.c:647-655) is scan-order state; it is dropped.
-template <bool COUNT>
+template <bool COUNT, bool RECTEST>
 __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const SOrigin *__restrict__ sorg,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
                                                 long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base, SplitP split) {
@@ -1695,7 +1722,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, own_sub, own_mask, ph,
+          stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
                         return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },
@@ -1705,12 +1732,13 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
                       },
                       [&](float k1, float k2) { kc = (in_group & (result >= 0.0f)) ? __builtin_fmaf(k1, onorm, k2) + g.slack : -INFINITY; },
                       [&](const float *R) {
+                        if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
                         const RecA A = rec_a(R);
                         PlTest t;
                         return pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
                       },
-                      [&](const float *R, uint32_t) {
-                        if (COUNT) { nWave++; if (kc != -INFINITY) nLane++; }
+                      [&](const float *R, uint32_t, bool first) {
+                        if (COUNT && first) { nWave++; if (kc != -INFINITY) nLane++; }
                         return test(R, a, r, pm, kc, current, dmax, [&](int verdict, float kt) {
                           if (verdict == 2) {
                             ts *= kt;  // every listing of a transparent triangle attenuates (:703-706)

@@ -115,6 +115,8 @@ struct rtgpu_ctx {
   unsigned long long *d_split_keys = nullptr, *d_split_masks = nullptr;
   uint32_t *d_split_done_n = nullptr, *d_split_done_s = nullptr;
   int opt_split_kernels = 3;  // option "split_kernels": bit 0 nearest walk, bit 1 shadow walk (diagnostic)
+  int opt_record_test = -1;  // option "record_test": the bundle's record-level test in the walk kernels; -1: where most of the scene is opaque
+  bool mostly_opaque = true;  // fewer than half of the scene's triangles are transparent (kt > 0)
   int opt_split = 0;  // option "split": 0 never, 1 as the queue length suggests, 2 / 4: every ticket, that many ways
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
   PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
@@ -459,6 +461,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
+  else if (!strcmp(name, "record_test")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "record_test: -1 (by the scene), 0 or 1"); c->opt_record_test = (int)value; }
   else if (!strcmp(name, "split_kernels")) c->opt_split_kernels = (int)value;
   else if (!strcmp(name, "split")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, RTGPU_E_INVALID_PARAM, "split: 0, 1, 2 or 4"); c->opt_split = (int)value; }
   else if (!strcmp(name, "queue_margin")) { if (value < 1 || value > 100000) return fail(c, RTGPU_E_INVALID_PARAM, "queue_margin out of range"); c->queue_margin_permille = (int)value; }
@@ -518,6 +521,11 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
     c->fan = f > c->fan ? f : c->fan;
   }
   c->levels = c->fan > 0 ? kMaxLevels : 1;
+  // Scenes of mostly transparent triangles keep their cells' lists in ascending order (the transparency product is
+  // taken in list order) and their shadow rays leave scattered points: bundles are wide against the triangles there.
+  size_t transparent = 0;
+  for (int t = 0; t < s->nt; t++) transparent += s->surfaces[s->sid[t]].kt > 0.0f ? 1 : 0;
+  c->mostly_opaque = 2 * transparent < (size_t)s->nt;
   c->chunk_tiles_cap = 0;
   c->have_ratio = false;
   for (int L = 0; L < kMaxLevels; L++) c->ratio[L] = L == 0 ? 1.0 : 0.0;
@@ -754,10 +762,12 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
     }
     {
       Span sp(c, W_NEAREST);
-      if (c->opt_count)
-        KLAUNCH(c, k_nearest<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split);
-      else
-        KLAUNCH(c, k_nearest<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split);
+      const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
+#define RT_LAUNCH_NEAREST(COUNT, RECTEST) \
+  KLAUNCH(c, (k_nearest<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split)
+      if (c->opt_count) { if (rectest) RT_LAUNCH_NEAREST(true, true); else RT_LAUNCH_NEAREST(true, false); }
+      else { if (rectest) RT_LAUNCH_NEAREST(false, true); else RT_LAUNCH_NEAREST(false, false); }
+#undef RT_LAUNCH_NEAREST
     }
     {
       Span sp(c, W_HIT);
@@ -818,10 +828,12 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       }
       Span sp(c, W_SHADOW);
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
-      if (c->opt_count)
-        KLAUNCH(c, k_shadow<true>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split);
-      else
-        KLAUNCH(c, k_shadow<false>, dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split);
+      const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
+#define RT_LAUNCH_SHADOW(COUNT, RECTEST) \
+  KLAUNCH(c, (k_shadow<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split)
+      if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW(true, true); else RT_LAUNCH_SHADOW(true, false); }
+      else { if (rectest) RT_LAUNCH_SHADOW(false, true); else RT_LAUNCH_SHADOW(false, false); }
+#undef RT_LAUNCH_SHADOW
     }
   }
   PrimaryP queued = c->prim;

@@ -62,6 +62,31 @@ def test_filter_on_and_off_give_the_same_frame(renderer, prefix, over, w, h, tex
     assert np.array_equal(on["minmax"].view(np.uint32), off["minmax"].view(np.uint32))
 
 
+@pytest.mark.parametrize("prefix,over,w,h,tex", CASES, ids=[c[0].split("/")[1] + ("_glass" if c[1] and "pokoj" in str(c[1]) else "") + "_%dx%d" % (c[2], c[3]) for c in CASES])
+def test_record_level_bundle_test_does_not_change_the_frame(renderer, prefix, over, w, h, tex):
+    """Option "record_test": the walk kernels drop, before a batch is staged, the records no ray of the wavefront's bundle
+    can pass (1), or test every record of a kept batch (0); -1 chooses by the scene.  Same frame, bit for bit, and the
+    same algorithmic counters."""
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    scene = rt.Scene(os.path.join(ROOT, prefix), texture=tex, width=w, height=h, **over)
+    frames = []
+    try:
+        for mode in (1, 0, -1):
+            renderer.set_option("record_test", mode)
+            frames.append(frame(renderer, scene, 1, count=True))
+    finally:
+        renderer.set_option("record_test", -1)
+    (a, ca) = frames[0]
+    for b, cb in frames[1:]:
+        assert np.array_equal(a["ids"], b["ids"])
+        assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+        assert np.array_equal(a["minmax"].view(np.uint32), b["minmax"].view(np.uint32))
+        for k in ("nearest_queries", "shadow_queries", "nearest_steps", "nearest_tests", "shadow_steps", "shadow_tests"):
+            assert ca[k] == cb[k], k
+    # with the test fewer records reach the ray-by-ray first slab
+    assert frames[0][1]["shadow_lane_slots"] <= frames[1][1]["shadow_lane_slots"]
+
+
 def test_filter_counters(renderer):
     scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=320, height=180)
     _, on = frame(renderer, scene, 1, count=True)
