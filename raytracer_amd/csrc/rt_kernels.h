@@ -126,43 +126,32 @@ RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, floa
 
 // For the batches of one header chunk and the rays of one bundle: an upper bound of 1 / |cos(ray, normal)|
 // over the batch's triangles, written into the LDS copy of each batch's header.  |cos| >= |axis.n| - rho for
-// the unit normal n.  A triangle the bundle may be coplanar with (bound below 1e-3, or below a quarter of the
-// batch's gb) makes the batch's value infinite: that batch is not culled in this visit.  One lane per record, 64 records per pass, the normals of
-// four passes loaded together (one memory latency); first = index of the chunk's first record, count = its records.
-struct NormalLoads { v4f x[4]; };
-RT_D NormalLoads normal_load4(const float *__restrict__ nrm, uint32_t first, uint32_t count, uint32_t p0, int lane) {
-  NormalLoads f;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const uint32_t p = p0 + 64u * q + (uint32_t)lane;
-    f.x[q] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    if (p < count) f.x[q] = *reinterpret_cast<const v4f *>(nrm + 4ull * (first + p));
-  }
-  return f;
+// the unit normal n, and the header's 10-bit normal is within 0.0017 of n.  A triangle the bundle may be coplanar with
+// (bound below 1e-3, or below a quarter of the batch's gb) makes the batch's value infinite: that batch is not culled in
+// this visit.  One lane per record, 64 records (8 headers) per pass; count = the chunk's records.
+RT_D uint32_t pack_normal(float x, float y, float z) {  // (a NaN or infinite component: the zero vector, no bound)
+  if (!(__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z) < 2.0f)) return 0u;
+  const int qx = (int)rintf(x * 511.0f), qy = (int)rintf(y * 511.0f), qz = (int)rintf(z * 511.0f);
+  return (uint32_t)(qx & 0x3ff) | (uint32_t)(qy & 0x3ff) << 10 | (uint32_t)(qz & 0x3ff) << 20;
 }
-RT_D void batch_cos(const float *__restrict__ nrm, uint32_t first, uint32_t count, float *hs, int lane, const Bundle &bu,
-                    NormalLoads f0) {
-  static_assert(kBatch == 16 || kBatch == 8, "a batch is a DPP row of 16 lanes or half of one");
-  NormalLoads f = f0;
-  for (uint32_t p0 = 0; p0 < count; p0 += 256) {
-    if (p0 != 0) f = normal_load4(nrm, first, count, p0, lane);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if (p0 + 64u * q >= count) break;
-      const uint32_t p = p0 + 64u * q + (uint32_t)lane;
-      const v4f x = f.x[q];
-      float c0 = INFINITY;  // lanes past the end of the list do not count
-      if (p < count) {
-        c0 = __builtin_fabsf(bu.axis.x * x.x + bu.axis.y * x.y + bu.axis.z * x.z);
-        if (!(c0 >= 0.0f)) c0 = 0.0f;  // a NaN must not be dropped by the min below
-      }
-      c0 = row_minmax16<false, kBatch>(c0);
-      const float cosb = c0 * 0.9999f - bu.rho;
-      if ((lane & (kBatch - 1)) == kBatch - 1 && p - (kBatch - 1) < count) {  // the last lane of a batch holds its minimum
-        float *H = hs + (p / kBatch) * kHdrFloats;
-        const float least = __builtin_fmaxf(0.001f, 0.25f * H[11]);  // gb / 4: below it det may change its sign by rounding
-        H[7] = cosb > least ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
-      }
+RT_D void batch_cos(uint32_t count, float *hs, int lane, const Bundle &bu) {
+  static_assert(kBatch == 8, "a batch is half a DPP row of 16 lanes");
+  const float sx = bu.axis.x * (1.0f / 511.0f), sy = bu.axis.y * (1.0f / 511.0f), sz = bu.axis.z * (1.0f / 511.0f);
+  for (uint32_t p0 = 0; p0 < count; p0 += 64) {
+    const uint32_t p = p0 + (uint32_t)lane;
+    float *H = hs + (p / kBatch) * kHdrFloats;
+    float c0 = INFINITY;  // lanes past the end of the list do not count
+    if (p < count) {
+      const uint32_t w = __float_as_uint(H[12 + (lane & (kBatch - 1))]);
+      const float nx = (float)((int)(w << 22) >> 22), ny = (float)((int)(w << 12) >> 22), nz = (float)((int)(w << 2) >> 22);
+      c0 = __builtin_fabsf(sx * nx + sy * ny + sz * nz);
+      if (!(c0 >= 0.0f)) c0 = 0.0f;  // a NaN must not be dropped by the min below
+    }
+    c0 = row_minmax16<false, kBatch>(c0);
+    const float cosb = c0 * 0.9999f - 0.0018f - bu.rho;
+    if ((lane & (kBatch - 1)) == kBatch - 1 && p - (kBatch - 1) < count) {  // the last lane of a batch holds its minimum
+      const float least = __builtin_fmaxf(0.001f, 0.25f * H[11]);  // gb / 4: below it det may change its sign by rounding
+      H[7] = cosb > least ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -402,16 +391,15 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
     if (((h0 / kHdrChunk) & own_mask) != own_sub) continue;  // a shared ticket: another wavefront tests this part of the list
     const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
-    static_assert(kHdrChunk * kHdrFloats / 4 <= 192, "up to three 16-byte loads per lane stage a header chunk");
-    if (lane < 3 * nh) glds16(hsrc + 3 * h0 + lane, hs);
-    if (lane + 64 < 3 * nh) glds16(hsrc + 3 * h0 + lane + 64, hs + 256);
-    if (kHdrChunk > 32 && lane + 128 < 3 * nh) glds16(hsrc + 3 * h0 + lane + 128, hs + 512);
+    constexpr int kHdrVecs = kHdrFloats / 4;
+    static_assert(kHdrChunk * kHdrVecs <= 192, "up to three 16-byte loads per lane stage a header chunk");
+    if (lane < kHdrVecs * nh) glds16(hsrc + kHdrVecs * h0 + lane, hs);
+    if (lane + 64 < kHdrVecs * nh) glds16(hsrc + kHdrVecs * h0 + lane + 64, hs + 256);
+    if (lane + 128 < kHdrVecs * nh) glds16(hsrc + kHdrVecs * h0 + lane + 128, hs + 512);
     {
-      const uint32_t first = h0 * kBatch, left = cnt - first;
-      const uint32_t count = left < (uint32_t)(kHdrChunk * kBatch) ? left : (uint32_t)(kHdrChunk * kBatch);
-      const NormalLoads f0 = normal_load4(g.cell_nrm, beg + first, count, 0u, lane);  // in flight together with the headers
+      const uint32_t left = cnt - h0 * kBatch;
       wait_staged();
-      batch_cos(g.cell_nrm, beg + first, count, hs, lane, bundle, f0);
+      batch_cos(left < (uint32_t)(kHdrChunk * kBatch) ? left : (uint32_t)(kHdrChunk * kBatch), hs, lane, bundle);
     }
     ph.template end<2>();
     // one lane per batch: can any ray of the bundle meet the batch's box at all?  If so the lane rewrites its header
@@ -901,7 +889,6 @@ __global__ void __launch_bounds__(256) k_grid_fill(int nt, GridP g, const uint32
 // centroids inside the cell (triangles larger than half a cell first), so that the 16 records of a batch
 // lie close together and their bounding sphere is small; all other lists keep the ascending order.
 // One block per cell; 64-bit keys (class, Morton code, position) sorted with a bitonic network in LDS.
-// Also writes the unit normals of the final order.
 constexpr int kSortMax = 4096, kSortThreads = 1024;
 RT_D uint32_t morton10(uint32_t x) {
   x &= 0x3ffu;
@@ -912,7 +899,7 @@ RT_D uint32_t morton10(uint32_t x) {
   return x;
 }
 __global__ void __launch_bounds__(kSortThreads) k_grid_sort(GridP g, const uint32_t *__restrict__ nonempty, const TriRec *__restrict__ src,
-                                                   TriRec *__restrict__ dst, float4 *__restrict__ nrm) {
+                                                   TriRec *__restrict__ dst) {
   __shared__ unsigned long long keys[kSortMax];
   __shared__ int transparent_s;
   if (blockIdx.x >= nonempty[g.ncells]) return;
@@ -974,9 +961,6 @@ __global__ void __launch_bounds__(kSortThreads) k_grid_sort(GridP g, const uint3
     float4 *D = reinterpret_cast<float4 *>(dst + beg + j);
 #pragma unroll
     for (int q = 0; q < kRecVecs; q++) D[q] = S[q];
-    const float4 n = S[0];  // n, k1
-    const float inv = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
-    nrm[beg + j] = make_float4(n.x * inv, n.y * inv, n.z * inv, 0.0f);  // NaN for a degenerate triangle: its batch never culls
   }
 }
 
@@ -1000,7 +984,9 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, const uint32_t *__
       k1 = R.k1; k2 = R.k2; transparent = R.kt > 0.0f ? 1.0f : 0.0f;
       // gb = 32 eps L^2 / |n|, ga = 0.9 gb L  (see box_test_bundle); L from k1 = 144 eps L
       const float L = R.k1 * (1.0f / (144.0f * 5.9604644775390625e-8f));
-      gb = (32.0f * 5.9604644775390625e-8f) * L * L / sqrtf(R.n[0] * R.n[0] + R.n[1] * R.n[1] + R.n[2] * R.n[2]) * 1.0001f;
+      const float nn = sqrtf(R.n[0] * R.n[0] + R.n[1] * R.n[1] + R.n[2] * R.n[2]), inv = 1.0f / nn;
+      hdrs[hbeg + (p - beg) / kBatch].normal[(p - beg) % kBatch] = pack_normal(R.n[0] * inv, R.n[1] * inv, R.n[2] * inv);
+      gb = (32.0f * 5.9604644775390625e-8f) * L * L / nn * 1.0001f;
       ga = 0.9f * gb * L * 1.0001f;
       if (!(gb >= 0.0f) || !(ga >= 0.0f)) bad = 1.0f;  // NaN (degenerate triangle): never cull this batch
       const float *G = g.geom + 9 * (long long)R.id;
@@ -1033,7 +1019,7 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, const uint32_t *__
 #pragma unroll
     for (int off = kBatch / 2; off > 0; off >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, off));
     if (valid && (lane & (kBatch - 1)) == 0) {
-      BatchHdr h;
+      BatchHdr &h = hdrs[hbeg + (p - beg) / kBatch];  // (its normals are written above, one per lane)
       h.c[0] = cx; h.c[1] = cy; h.c[2] = cz;
       const float cn = sqrtf(cx * cx + cy * cy + cz * cz);
       h.radius = bad != 0.0f ? INFINITY : (sqrtf(r2) * 1.001f + 0.00001f * cn) * 1.0001f + 1e-30f;
@@ -1042,7 +1028,6 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, const uint32_t *__
       h.inv_cos = INFINITY;
       h.k1 = k1; h.k2 = transparent != 0.0f ? -k2 : k2;  // k2 > 0 (rt_math.h)
       h.ga = ga; h.gb = gb;
-      hdrs[hbeg + (p - beg) / kBatch] = h;
     }
   }
 }

@@ -41,15 +41,17 @@ static_assert(kBatch == 8 || kBatch == 16 || kBatch == 32 || kBatch == 64, "a wa
 constexpr int kHdrChunk = RT_HDR_CHUNK;  // batch headers staged in LDS at a time (one lane per header in the bundle test)
 static_assert(kHdrChunk == 32 || kHdrChunk == 64, "the masks of a header chunk are 64 bits wide");
 static_assert(kHdrChunk * kBatch == 256, "a header chunk covers 256 records: the unit by which shared tickets divide a list (kOwnShift)");
-constexpr int kHdrFloats = 12;
+constexpr int kHdrFloats = 20;
 
 // Header of one batch (positions kBatch*b .. kBatch*b + kBatch-1 of a cell's list): the axis-aligned box
 // (centre c, half extents h) and the sphere (c, radius) that contain every triangle of the batch, both already
 // inflated for rounding; the maxima of the records' k1, k2, with k2 negated if any triangle of the batch is
-// transparent (kt > 0); and the batch's constants ga, gb of the bound of what rounding can add to the box
-// (box_test_bundle in rt_kernels.h).  inv_cos is scratch: the walk kernels keep the visit's bound of
-// 1 / |cos(ray, normal)| for the batch there, in their LDS copy, and for a batch the bundle test lets through they
-// overwrite radius, h and inv_cos of that copy with -+delta, h + W and W for the ray-by-ray test.
+// transparent (kt > 0); the batch's constants ga, gb of the bound of what rounding can add to the box
+// (box_test_bundle in rt_kernels.h); and the unit normals of the batch's triangles, three signed 10-bit fractions
+// (units of 1/511) in a word each: within 0.0017 of the normal, all zero for a degenerate triangle.  inv_cos is scratch:
+// the walk kernels keep the visit's bound of 1 / |cos(ray, normal)| for the batch there, in their LDS copy, and for a
+// batch the bundle test lets through they overwrite radius, h and inv_cos of that copy with -+delta, h + W and W for the
+// ray-by-ray test, ga with the bundle's distance bound and gb with one bit per record the bundle's record-level test leaves.
 struct __attribute__((aligned(16))) BatchHdr {
   float c[3];
   float radius;
@@ -57,8 +59,10 @@ struct __attribute__((aligned(16))) BatchHdr {
   float inv_cos;
   float k1, k2;
   float ga, gb;
+  uint32_t normal[8];
 };
-static_assert(sizeof(BatchHdr) == 4 * kHdrFloats, "BatchHdr is 48 bytes");
+static_assert(kBatch == 8, "a batch header holds the normals of 8 records");
+static_assert(sizeof(BatchHdr) == 4 * kHdrFloats, "BatchHdr is 80 bytes");
 
 // Uniform grid ("UDD", src/voxelize.h:21-25) plus the grown scene domain.
 struct GridP {
@@ -71,7 +75,6 @@ struct GridP {
   const TriRec *cell_tris;
   const uint32_t *hdr_start;   // ncells+1 offsets into cell_hdrs (one header per kBatch records of a cell)
   const BatchHdr *cell_hdrs;
-  const float *cell_nrm;       // unit normal of every listed triangle (4 floats per reference, list order)
   const float *geom;           // per triangle i, ij, ik (9 floats)
   const float *filt;           // per triangle kRecFloats floats: a TriRec with the triangle's own k1, k2
   float lmax;                  // longest triangle edge of the scene (upper bound)

@@ -63,7 +63,6 @@ struct rtgpu_ctx {
   PlanarD *d_planar = nullptr;
   uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr /* list of the non-empty cells */, *d_hdr_start = nullptr, *d_occ = nullptr;
   BatchHdr *d_hdrs = nullptr;
-  float4 *d_nrm = nullptr;
   size_t cap_hdrs = 0;
   TriRec *d_recs = nullptr, *d_recs_unsorted = nullptr;
   size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
@@ -78,8 +77,7 @@ struct rtgpu_ctx {
     float *d_geom = nullptr, *d_aux = nullptr;
     uint32_t *d_cell_start = nullptr, *d_hdr_start = nullptr, *d_occ = nullptr;
     BatchHdr *d_hdrs = nullptr;
-    float4 *d_nrm = nullptr;
-    TriRec *d_recs = nullptr;
+      TriRec *d_recs = nullptr;
     int32_t *d_refs = nullptr;
   } alt;
   hipStream_t build_stream = nullptr;
@@ -174,7 +172,7 @@ void dev_free(T **p) {
 void swap_grid_sets(rtgpu_ctx *c) {
   std::swap(c->d_geom, c->alt.d_geom); std::swap(c->d_aux, c->alt.d_aux);
   std::swap(c->d_cell_start, c->alt.d_cell_start); std::swap(c->d_hdr_start, c->alt.d_hdr_start); std::swap(c->d_occ, c->alt.d_occ);
-  std::swap(c->d_hdrs, c->alt.d_hdrs); std::swap(c->d_nrm, c->alt.d_nrm); std::swap(c->d_recs, c->alt.d_recs);
+  std::swap(c->d_hdrs, c->alt.d_hdrs); std::swap(c->d_recs, c->alt.d_recs);
   std::swap(c->d_refs, c->alt.d_refs);
   c->parity ^= 1;
 }
@@ -423,14 +421,14 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   if (c->build_stream) (void)hipStreamSynchronize(c->build_stream);
   resolve_spans(c);
   dev_free(&c->alt.d_geom); dev_free(&c->alt.d_aux); dev_free(&c->alt.d_cell_start); dev_free(&c->alt.d_hdr_start); dev_free(&c->alt.d_occ);
-  dev_free(&c->alt.d_hdrs); dev_free(&c->alt.d_nrm); dev_free(&c->alt.d_recs); dev_free(&c->alt.d_refs);
+  dev_free(&c->alt.d_hdrs); dev_free(&c->alt.d_recs); dev_free(&c->alt.d_refs);
   if (c->ev_built) (void)hipEventDestroy(c->ev_built);
   for (int k = 0; k < 2; k++) if (c->ev_released[k]) (void)hipEventDestroy(c->ev_released[k]);
   if (c->build_stream) (void)hipStreamDestroy(c->build_stream);
   dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs); dev_free(&c->d_recs_unsorted);
-  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_nrm);
+  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba);
@@ -608,7 +606,7 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   if (piped && c->released_valid[c->parity]) HIPCHK(c, hipStreamWaitEvent(bs, c->ev_released[c->parity], 0));
   GridP g;
   for (int k = 0; k < 3; k++) { g.dmin[k] = dmin[k]; g.dmax[k] = dmax[k]; g.cs[k] = cs[k]; g.nv[k] = nv[k]; }
-  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.occ = c->d_occ; g.occ_box = reinterpret_cast<const int32_t *>(c->d_occ + ((size_t)ncells / 32 + 1)); g.cell_hdrs = nullptr; g.cell_nrm = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
+  g.ncells = ncells; g.cell_start = c->d_cell_start; g.cell_tris = nullptr; g.hdr_start = c->d_hdr_start; g.occ = c->d_occ; g.occ_box = reinterpret_cast<const int32_t *>(c->d_occ + ((size_t)ncells / 32 + 1)); g.cell_hdrs = nullptr; g.geom = c->d_geom; g.filt = c->d_filt; g.lmax = c->lmax; g.slack = 0.0f;
   const int tb = 256, tblocks = (c->nt + tb - 1) / tb;
   {
     Span sp(c, W_PRE, bs);
@@ -639,9 +637,8 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     }
     if ((size_t)nrefs > c->cap_refs) {
       if ((rc = dev_alloc(c, &c->d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_recs_unsorted, (size_t)nrefs)) ||
-          (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->d_nrm, (size_t)nrefs)) ||
-          (rc = dev_alloc(c, &c->alt.d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->alt.d_refs, (size_t)nrefs)) ||
-          (rc = dev_alloc(c, &c->alt.d_nrm, (size_t)nrefs))) return rc;
+          (rc = dev_alloc(c, &c->d_refs, (size_t)nrefs)) ||
+          (rc = dev_alloc(c, &c->alt.d_recs, (size_t)nrefs)) || (rc = dev_alloc(c, &c->alt.d_refs, (size_t)nrefs))) return rc;
       c->cap_refs = nrefs;
     }
     // one header per kBatch records of a cell: at most nrefs / kBatch full batches plus one partial batch per non-empty cell
@@ -652,10 +649,9 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     }
     g.cell_tris = c->d_recs;
     g.cell_hdrs = c->d_hdrs;
-    g.cell_nrm = reinterpret_cast<const float *>(c->d_nrm);
     if (nonempty > 0) {  // d_nbatch holds the list of the non-empty cells, its length at [ncells]
       KLAUNCH(c, k_grid_fill, dim3((nonempty + 3) / 4), dim3(256), bs, c->nt, g, c->d_nbatch, c->d_box, c->d_recs_unsorted, c->d_refs);
-      KLAUNCH(c, k_grid_sort, dim3(nonempty), dim3(kSortThreads), bs, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs, c->d_nrm);
+      KLAUNCH(c, k_grid_sort, dim3(nonempty), dim3(kSortThreads), bs, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs);
       KLAUNCH(c, k_grid_bounds, dim3(nonempty), dim3(256), bs, g, c->d_nbatch, c->d_hdrs);
     }
   }

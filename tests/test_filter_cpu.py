@@ -118,20 +118,24 @@ def batch_header(T):
         gb = (F(32.0 * EPS) * L * L / nn * F(1.0001)).astype(F)
         ga = (F(0.9) * gb * L * F(1.0001)).astype(F)
         nrm = (N * (F(1.0) / nn)[:, None]).astype(F)
+        # the header's normal: three signed 10-bit fractions (pack_normal), the zero vector for a degenerate triangle
+        ok = np.abs(nrm).sum(1) < 2
+        nq = np.where(ok[:, None], np.rint(np.where(ok[:, None], nrm, 0) * F(511.0)), 0).astype(F)
     bad = ~((gb >= 0) & (ga >= 0))
     radius = np.where(bad, F(np.inf), radius)
     h = ((F(0.5) * (hi - lo) * F(1.001) + F(0.00001) * cn[:, None]) * F(1.0001) + F(1e-30)).astype(F)
     h = np.where(bad[:, None], F(np.inf), h)
-    return dict(c=c, radius=radius, h=h, ga=ga, gb=gb, nrm=nrm)
+    return dict(c=c, radius=radius, h=h, ga=ga, gb=gb, nq=nq)
 
 
 def batch_cos(H, axis, rho):
     """batch_cos of rt_kernels.h for batches of one triangle: bound of 1 / |cos(ray, normal)| over a bundle."""
-    n = H["nrm"]
+    n = H["nq"]
     with np.errstate(all="ignore"):
-        c0 = np.abs(axis[:, 0] * n[:, 0] + axis[:, 1] * n[:, 1] + axis[:, 2] * n[:, 2])
+        s = (axis * F(1.0 / 511.0)).astype(F)
+        c0 = np.abs(s[:, 0] * n[:, 0] + s[:, 1] * n[:, 1] + s[:, 2] * n[:, 2])
         c0 = np.where(c0 >= 0, c0, F(0))
-        cosb = c0 * F(0.9999) - rho
+        cosb = c0 * F(0.9999) - F(0.0018) - rho
         least = np.maximum(F(0.001), F(0.25) * H["gb"])
         return np.where(cosb > least, (F(1.0) / cosb).astype(F) * F(1.01), F(np.inf)).astype(F)
 
