@@ -34,7 +34,7 @@ for k in sorted(acc):
 
 out = {}
 for k in acc:
-    for fam in ("k_shadow<false>", "k_nearest<false>"):
+    for fam in ("k_shadow<false", "k_nearest<false"):
         if fam in k:
             out[fam.split("<")[0]] = {c: sum(v) / len(v) for c, v in acc[k].items()}
 if out:
