@@ -147,6 +147,9 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * what the scene's chunks produce, which costs one host synchronisation per chunk, and a chunk whose queues turn out too small
  * is rendered again with worst-case queues; 0: always worst case, 31 nodes per pixel at depth 5, no synchronisation),
  * "queue_margin" (default 1500: queues are planned for the largest ratio seen so far x 1.5; in permille),
+ * "order" (default 1: the shaded hits of every recursion level below the first get their shadow walks and colours in the order
+ * of the grid cells their hit points lie in, so that a wavefront's 64 shadow rays start close together; 0: in queue order;
+ * 2: the first level too; same image),
  * "record_test" (default -1: by the scene; 1 / 0: the walk kernels test the records of a batch against the whole bundle of a
  * wavefront's rays before they stage the batch, or do not: same image either way; it pays where bundles are narrow against
  * the triangles, and -1 switches it on unless half of the scene's triangles or more are transparent),

@@ -2,7 +2,8 @@
 //
 // Frame set-up          k_preprocess, k_tri_boxes -> k_grid_offsets -> k_grid_fill -> k_grid_sort -> k_grid_bounds
 // Pixel loop (a chunk)  k_chunk_init -> [k_nearest -> k_hit] per recursion level (level 0 computes its primary rays)
-//                       [-> k_subtree_hits, k_tree_starts, k_assign_ranks with planar lights] -> k_shadow per level
+//                       [-> k_subtree_hits, k_tree_starts, k_assign_ranks with planar lights]
+//                       -> [k_order_count -> k_order_scan -> k_order_place below level 0 ->] k_shadow per level
 //                       -> k_accumulate per level, deepest first (level 0 folds the colour range of its blocks) -> k_minmax_final
 // After the exchange    k_tonemap, k_untile, k_bmp_rows
 #pragma once
@@ -1397,6 +1398,73 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// The order in which a level's nodes get their shadow walks and their colours: by the cell of the hit point, so that the
+// 64 nodes of a shadow ticket start their walks close together whatever pixels they come from (the nodes of a level
+// below 0 are appended in the order their rays were spawned: neighbours in the queue are neighbours on the surface the
+// parent rays left, not on the one they hit).  Nodes without a hit come last.  A counting sort in three launches:
+// nodes per cell, an exclusive scan over the cells, positions handed out cell by cell.  The order inside a cell is
+// whatever the atomics make it; no result depends on it (a node's walks and colour are its own).
+RT_D uint32_t node_cell(const GridP &g, const SOrigin &nd) {
+  int i, j, k;
+  if (nd.tri < 0 || !voxel_of(g, ld3(nd.p), i, j, k)) return (uint32_t)g.ncells;  // no hit (or a hit point outside the grid): the last bucket
+  return (uint32_t)cell_index(g, i, j, k);
+}
+// adds one per active lane to bucket[key], one atomic per distinct key of the wavefront; returns the lane's position
+RT_D uint32_t bucket_take(uint32_t *bucket, uint32_t key, bool active, int lane) {
+  uint32_t pos = 0;
+  unsigned long long todo = __ballot(active);
+  while (todo != 0) {
+    const int first = __ffsll(todo) - 1;
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+    const unsigned long long same = __ballot(active && key == k);
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&bucket[k], (uint32_t)__popcll(same));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+    if (active && key == k) pos = base + (uint32_t)__popcll(same & lanes_below(lane));
+    todo &= ~same;
+  }
+  return pos;
+}
+__global__ void __launch_bounds__(256) k_order_count(GridP g, const SOrigin *__restrict__ sorg, const Ctl *__restrict__ ctl, int level,
+                                                     int node_base, uint32_t *__restrict__ bucket) {
+  const int n = queue_len(ctl, level), lane = lane_id();
+  for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t key = valid ? node_cell(g, sorg[node_base + i]) : 0u;
+    (void)bucket_take(bucket, key, valid, lane);
+  }
+}
+// exclusive scan of bucket[0 .. nb-1] in place, one block
+__global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ bucket, int nb) {
+  __shared__ uint32_t part[1024];
+  const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+  uint32_t sum = 0;
+  for (int q = lo; q < hi; q++) sum += bucket[q];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (int q = lo; q < hi; q++) { const uint32_t v = bucket[q]; bucket[q] = run; run += v; }
+}
+__global__ void __launch_bounds__(256) k_order_place(GridP g, const SOrigin *__restrict__ sorg, const Ctl *__restrict__ ctl, int level,
+                                                     int node_base, uint32_t *__restrict__ bucket, uint32_t *__restrict__ order) {
+  const int n = queue_len(ctl, level), lane = lane_id();
+  for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t key = valid ? node_cell(g, sorg[node_base + i]) : 0u;
+    const uint32_t pos = bucket_take(bucket, key, valid, lane);
+    if (valid) order[node_base + pos] = (uint32_t)i;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Hit kernel (raytrace.c:170-204): turns the hits of one level into shaded-hit records and emits the
 // secondary rays.  Normal flip, surface colour, procedural texture + bump (fused here), reflected and
 // refracted rays.  Children are appended to the next level's queue with one atomic per wavefront
@@ -1573,7 +1641,8 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 template <bool COUNT, bool RECTEST>
 __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const SOrigin *__restrict__ sorg,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
-                                                long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base, SplitP split) {
+                                                long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base, SplitP split,
+                                                const uint32_t *__restrict__ order) {
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
@@ -1604,7 +1673,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     RT_TICKET(TicketLog tl; tl.begin();)
     const long long item = (long long)base + lane;
     bool alive = false;
-    int slot = 0, nidx = 0, current = -1;
+    int slot = 0, nidx = 0, current = -1, where = 0;
     f3 a = mk3(0, 0, 0), r = mk3(0, 0, 0), pm = mk3(0, 0, 0);  // pm = a x r, onorm >= |a|: the filter's ray side
     float dmax = 0.0f, ts = 1.0f, result = 1.0f, onorm = 0.0f, odr = 0.0f;
     bool have_result = false;
@@ -1621,6 +1690,9 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         slot = (int)(slot0 + rest / (uint32_t)n);
         nidx = (int)(rest % (uint32_t)n);
       }
+      const int at = nidx;  // the node's place in the level's order: where its results go
+      if (order) nidx = (int)order[node_base + at];
+      where = node_base + at;
       const SOrigin nd = sorg[node_base + nidx];
       current = nd.tri;
       if (current >= 0) {
@@ -1813,14 +1885,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         if (lane == 0) all = atomicOr(mask, 0ull);  // reads the mask where the other shares' atomics put it
         all = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(all >> 32)) << 32) |
               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)all);  // (readfirstlane gives a signed int)
-        if (have_result) ts_out[(long long)slot * ts_stride + (node_base + nidx)] = ((all >> lane) & 1ull) ? -1.0f : ts;
+        if (have_result) ts_out[(long long)slot * ts_stride + where] = ((all >> lane) & 1ull) ? -1.0f : ts;
       }
     } else if (have_result) {
       // slot-major: the 64 lanes of a ticket are consecutive hits of one slot, so the store is one 256-byte line
 #ifdef RT_HIST
-      ts_out[(long long)slot * ts_stride + (node_base + nidx)] = result < 0.0f ? result : ts;  // (diagnostic build: the blocker stays visible)
+      ts_out[(long long)slot * ts_stride + where] = result < 0.0f ? result : ts;  // (diagnostic build: the blocker stays visible)
 #else
-      ts_out[(long long)slot * ts_stride + (node_base + nidx)] = result < 0.0f ? -1.0f : ts;
+      ts_out[(long long)slot * ts_stride + where] = result < 0.0f ? -1.0f : ts;
 #endif
     }
     RT_TICKET(ph.end<0>(); if (level == 0) tl.end(1, base, lane, ph); busy += __builtin_amdgcn_s_memtime() - tl.t0;)
@@ -1877,15 +1949,16 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
                                                     const float *__restrict__ ts_in, long long ts_stride, const int32_t *__restrict__ rand_rank,
                                                     float *__restrict__ colors, Ctl *__restrict__ ctl, int level,
                                                     int node_base, float *__restrict__ fb_rgb, int32_t *__restrict__ fb_ids,
-                                                    long long fb_base, float *__restrict__ partial, PrimaryP prim) {
+                                                    long long fb_base, float *__restrict__ partial, PrimaryP prim, const uint32_t *__restrict__ order) {
   const int n = queue_len(ctl, level);
   const bool fold = level == 0 && partial != nullptr;  // level 0 also folds the colour range of the block's pixels
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {FLT_MIN, FLT_MIN, FLT_MIN};
   // block-stride loop (the launches of the levels below 0 are sized for the queue's capacity, cut at a few thousand blocks)
   for (int idx0 = blockIdx.x * blockDim.x; idx0 < n; idx0 += gridDim.x * blockDim.x) {
-  const int idx = idx0 + threadIdx.x;
-  const bool valid = idx < n;
+  const int at = idx0 + threadIdx.x;  // place in the level's order: where the shadow walks left this node's results
+  const bool valid = at < n;
   if (!valid) continue;
+  const int idx = order ? (int)order[node_base + at] : at;
   const int gidx = node_base + idx;
   const Node nd = nodes[gidx];
   f3 res = mk3(0.0f, 0.0f, 0.0f);
@@ -1903,7 +1976,7 @@ __global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__rest
       f3 rc = nd.refr >= 0 ? ld3(colors + 4ll * nd.refr) : mk3(0.0f, 0.0f, 0.0f);
       res = add3(res, mul3(rc, sf.kt));
     }
-    const float *ts = ts_in + gidx;  // slot s of this node: ts[s * ts_stride]
+    const float *ts = ts_in + node_base + at;  // slot s of this node: ts[s * ts_stride]
     f3 tmp = mk3(0.0f, 0.0f, 0.0f);
     for (int c = 0; c < sp.nl; c++) {
       const float t = ts[c * ts_stride];

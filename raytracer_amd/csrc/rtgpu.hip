@@ -61,6 +61,7 @@ struct rtgpu_ctx {
   SurfaceD *d_surf = nullptr;
   LightD *d_lights = nullptr;
   PlanarD *d_planar = nullptr;
+  uint32_t *d_bucket = nullptr;  // nodes per cell, then positions: the order of a level's shadow work (k_order_*)
   uint32_t *d_counts = nullptr, *d_cell_start = nullptr, *d_nbatch = nullptr /* list of the non-empty cells */, *d_hdr_start = nullptr, *d_occ = nullptr;
   BatchHdr *d_hdrs = nullptr;
   size_t cap_hdrs = 0;
@@ -119,6 +120,8 @@ struct rtgpu_ctx {
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
   PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
   int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
+  uint32_t *d_order = nullptr;  // per level below 0: its nodes by the cell of their hit point (k_order_place)
+  int opt_order = 1;  // option "order": 0 queue order everywhere, 1 the levels below 0 by cell, 2 level 0 too
   Ctl *d_ctl = nullptr;
   unsigned char *scratch = nullptr;  // this device's copy of the static scratch array (rtgpu_render_static)
   unsigned long long *d_totals = nullptr;  // [kStatCount + kMaxLevels + 1]
@@ -262,6 +265,7 @@ int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
   if ((rc = give((void **)&c->d_partial, sizeof(float) * ((tiles * kTilePixels + 255) / 256 * 6)))) return rc;  // colour range per block of level 0
   const size_t nrank = c->npl > 0 ? total : 1;
   if ((rc = give((void **)&c->d_rank, sizeof(int32_t) * nrank)) || (rc = give((void **)&c->d_size, sizeof(int32_t) * nrank))) return rc;
+  if ((rc = give((void **)&c->d_order, sizeof(uint32_t) * (c->levels > 1 || c->opt_order > 1 ? total : 1)))) return rc;
   // shared tickets exist only in scenes without secondary rays (one level, no transparent triangle)
   const size_t st = c->fan == 0 ? tiles : 0, ss = st * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1);
   if ((rc = give((void **)&c->d_split_keys, sizeof(unsigned long long) * (st * kTilePixels + 1))) ||
@@ -306,14 +310,14 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
 struct QueueSet {
   size_t chunk_tiles_cap, cap[kMaxLevels], base[kMaxLevels], total_nodes;
   unsigned long long *d_split_keys, *d_split_masks; uint32_t *d_split_done_n, *d_split_done_s;
-  Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; SOrigin *d_sorg; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size;
+  Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; SOrigin *d_sorg; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size; uint32_t *d_order;
 };
 QueueSet take_queues(rtgpu_ctx *c) {
   QueueSet q;
   q.chunk_tiles_cap = c->chunk_tiles_cap; q.total_nodes = c->total_nodes;
   for (int L = 0; L < kMaxLevels; L++) { q.cap[L] = c->cap[L]; q.base[L] = c->base[L]; q.d_rays[L] = c->d_rays[L]; c->d_rays[L] = nullptr; }
   q.d_hits = c->d_hits; q.d_nodes = c->d_nodes; q.d_sorg = c->d_sorg; q.d_colors = c->d_colors; q.d_ts = c->d_ts; q.d_partial = c->d_partial;
-  q.d_rank = c->d_rank; q.d_size = c->d_size;
+  q.d_rank = c->d_rank; q.d_size = c->d_size; q.d_order = c->d_order; c->d_order = nullptr;
   q.d_split_keys = c->d_split_keys; q.d_split_masks = c->d_split_masks; q.d_split_done_n = c->d_split_done_n; q.d_split_done_s = c->d_split_done_s;
   c->d_split_keys = c->d_split_masks = nullptr; c->d_split_done_n = c->d_split_done_s = nullptr;
   c->d_hits = nullptr; c->d_nodes = nullptr; c->d_sorg = nullptr; c->d_colors = c->d_ts = c->d_partial = nullptr; c->d_rank = c->d_size = nullptr;
@@ -323,7 +327,7 @@ void put_queues(rtgpu_ctx *c, const QueueSet &q) {
   c->chunk_tiles_cap = q.chunk_tiles_cap; c->total_nodes = q.total_nodes;
   for (int L = 0; L < kMaxLevels; L++) { c->cap[L] = q.cap[L]; c->base[L] = q.base[L]; c->d_rays[L] = q.d_rays[L]; }
   c->d_hits = q.d_hits; c->d_nodes = q.d_nodes; c->d_sorg = q.d_sorg; c->d_colors = q.d_colors; c->d_ts = q.d_ts; c->d_partial = q.d_partial;
-  c->d_rank = q.d_rank; c->d_size = q.d_size;
+  c->d_rank = q.d_rank; c->d_size = q.d_size; c->d_order = q.d_order;
   c->d_split_keys = q.d_split_keys; c->d_split_masks = q.d_split_masks; c->d_split_done_n = q.d_split_done_n; c->d_split_done_s = q.d_split_done_s;
 }
 
@@ -347,7 +351,7 @@ size_t bytes_per_tile(const rtgpu_ctx *c) {
     nodes += capL;
     maxcap = capL > maxcap ? capL : maxcap;
   }
-  const double b = nodes * (double)(sizeof(Ray) + sizeof(Node) + sizeof(SOrigin) + 16 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) -
+  const double b = nodes * (double)(sizeof(Ray) + sizeof(Node) + sizeof(SOrigin) + 16 + 4 + 4 * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1)) -
                    (double)(kTilePixels * sizeof(Ray)) + maxcap * (double)sizeof(Hit) + kTilePixels * 4.0;  // (no ray queue for level 0)
   return (size_t)ceil(b);
 }
@@ -428,11 +432,11 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_verts); dev_free(&c->d_geom); dev_free(&c->d_aux); dev_free(&c->d_filt); dev_free(&c->d_sid); dev_free(&c->d_box);
   dev_free(&c->d_refs); dev_free(&c->d_rand); dev_free(&c->d_surf); dev_free(&c->d_lights); dev_free(&c->d_planar);
   dev_free(&c->d_counts); dev_free(&c->d_cell_start); dev_free(&c->d_recs); dev_free(&c->d_recs_unsorted);
-  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs);
+  dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_bucket);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba);
-  dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_split_keys); dev_free(&c->d_split_masks); dev_free(&c->d_split_done_n); dev_free(&c->d_split_done_s); dev_free(&c->d_ctl); dev_free(&c->d_totals);
+  dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_order); dev_free(&c->d_split_keys); dev_free(&c->d_split_masks); dev_free(&c->d_split_done_n); dev_free(&c->d_split_done_s); dev_free(&c->d_ctl); dev_free(&c->d_totals);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -460,6 +464,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
   else if (!strcmp(name, "record_test")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "record_test: -1 (by the scene), 0 or 1"); c->opt_record_test = (int)value; }
+  else if (!strcmp(name, "order")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "order: 0, 1 or 2"); if ((int)value != c->opt_order) c->chunk_tiles_cap = 0; c->opt_order = (int)value; }
   else if (!strcmp(name, "split_kernels")) c->opt_split_kernels = (int)value;
   else if (!strcmp(name, "split")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, RTGPU_E_INVALID_PARAM, "split: 0, 1, 2 or 4"); c->opt_split = (int)value; }
   else if (!strcmp(name, "queue_margin")) { if (value < 1 || value > 100000) return fail(c, RTGPU_E_INVALID_PARAM, "queue_margin out of range"); c->queue_margin_permille = (int)value; }
@@ -594,6 +599,7 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->d_nbatch, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_hdr_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->d_occ, (size_t)ncells / 32 + 1 + 8)) ||  // + the box of the non-empty cells
+        (rc = dev_alloc(c, &c->d_bucket, (size_t)ncells + 2)) ||
         (rc = dev_alloc(c, &c->alt.d_cell_start, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->alt.d_hdr_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->alt.d_occ, (size_t)ncells / 32 + 1 + 8))) return rc;
     c->cap_cells = (size_t)ncells + 1;
@@ -806,6 +812,12 @@ int chunk_ranks(rtgpu_ctx *c, int n0, const int32_t *sizes, int64_t per_rank, in
   return RTGPU_OK;
 }
 
+// The order in which level L's nodes are shaded (option "order"), or null: queue order.
+const uint32_t *level_order(const rtgpu_ctx *c, int L) {
+  if (c->shade.nslots <= 0 || c->opt_order == 0 || (L == 0 && c->opt_order < 2)) return nullptr;
+  return c->d_order;
+}
+
 // Second half: shadow walks, colours deepest level first, colour range, statistics.
 int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d_ids, float *d_minmax) {
   const int n0 = nt_chunk * kTilePixels;
@@ -823,10 +835,18 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
         }
       }
       Span sp(c, W_SHADOW);
+      const uint32_t *order = level_order(c, L);
+      if (order) {  // this level's nodes by the cell of their hit point
+        const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
+        HIPCHK(c, hipMemsetAsync(c->d_bucket, 0, sizeof(uint32_t) * ((size_t)c->grid.ncells + 2), c->stream));
+        KLAUNCH(c, k_order_count, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->d_sorg, (const Ctl *)c->d_ctl, L, (int)c->base[L], c->d_bucket);
+        KLAUNCH(c, k_order_scan, dim3(1), dim3(1024), c->stream, c->d_bucket, c->grid.ncells + 1);
+        KLAUNCH(c, k_order_place, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->d_sorg, (const Ctl *)c->d_ctl, L, (int)c->base[L], c->d_bucket, c->d_order);
+      }
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
 #define RT_LAUNCH_SHADOW(COUNT, RECTEST) \
-  KLAUNCH(c, (k_shadow<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split)
+  KLAUNCH(c, (k_shadow<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split, order)
       if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW(true, true); else RT_LAUNCH_SHADOW(true, false); }
       else { if (rectest) RT_LAUNCH_SHADOW(false, true); else RT_LAUNCH_SHADOW(false, false); }
 #undef RT_LAUNCH_SHADOW
@@ -840,7 +860,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
     KLAUNCH(c, k_accumulate, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->shade, c->d_rays[L], c->d_nodes,
                        c->d_ts, (long long)c->total_nodes, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
                        L == 0 ? c->d_partial : nullptr,  // level 0 (the last one) also folds the colour range of its blocks
-                       L == 0 ? c->prim : queued);
+                       L == 0 ? c->prim : queued, level_order(c, L));
   }
   {
     Span sp(c, W_MINMAX);

@@ -134,3 +134,28 @@ def test_tickets_shared_by_several_wavefronts_do_not_change_the_frame(prefix, ov
         assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
         assert np.array_equal(a["minmax"].view(np.uint32), b["minmax"].view(np.uint32))
 
+
+
+@pytest.mark.parametrize("prefix,over,w,h,tex", [c for c in CASES if "ulica" in c[0] or "pokoj" in str(c) or "s2/s2" in c[0] or c[2] == 333],
+                         ids=lambda v: None)
+def test_order_of_shading_does_not_change_the_frame(renderer, prefix, over, w, h, tex):
+    """Option "order": the shaded hits of a recursion level get their shadow walks and colours in queue order (0), by
+    the grid cell of the hit point below the first level (1, the default) or on every level (2).  A node's walks and
+    colour are its own: same frame bit for bit, same counters."""
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    scene = rt.Scene(os.path.join(ROOT, prefix), texture=tex, width=w, height=h, **over)
+    frames = []
+    try:
+        for mode in (0, 1, 2):
+            renderer.set_option("order", mode)
+            frames.append(frame(renderer, scene, 1, count=True))
+    finally:
+        renderer.set_option("order", 1)
+    (a, ca) = frames[0]
+    assert (a["ids"] >= 0).any()
+    for b, cb in frames[1:]:
+        assert np.array_equal(a["ids"], b["ids"])
+        assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+        assert np.array_equal(a["minmax"].view(np.uint32), b["minmax"].view(np.uint32))
+        for k in ("nearest_queries", "shadow_queries", "nearest_steps", "nearest_tests", "shadow_steps", "shadow_tests"):
+            assert ca[k] == cb[k], k
