@@ -149,7 +149,8 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * "queue_margin" (default 1500: queues are planned for the largest ratio seen so far x 1.5; in permille),
  * "order" (default 1: the shaded hits of every recursion level below the first get their shadow walks and colours in the order
  * of the grid cells their hit points lie in, so that a wavefront's 64 shadow rays start close together; 0: in queue order;
- * 2: the first level too; same image),
+ * 2: the first level too; same image), "order_parts" (default 8: that order distinguishes this many parts of a cell along each
+ * axis, as far as 2^25 buckets allow; 1, 2, 4 or 8),
  * "record_test" (default -1: by the scene; 1 / 0: the walk kernels test the records of a batch against the whole bundle of a
  * wavefront's rays before they stage the batch, or do not: same image either way; it pays where bundles are narrow against
  * the triangles, and -1 switches it on unless half of the scene's triangles or more are transparent),

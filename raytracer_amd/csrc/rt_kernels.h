@@ -1401,13 +1401,17 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
 // The order in which a level's nodes get their shadow walks and their colours: by the cell of the hit point, so that the
 // 64 nodes of a shadow ticket start their walks close together whatever pixels they come from (the nodes of a level
 // below 0 are appended in the order their rays were spawned: neighbours in the queue are neighbours on the surface the
-// parent rays left, not on the one they hit).  Nodes without a hit come last.  A counting sort in three launches:
-// nodes per cell, an exclusive scan over the cells, positions handed out cell by cell.  The order inside a cell is
+// parent rays left, not on the one they hit).  Nodes without a hit come last.  A counting sort: nodes per bucket (a
+// part of a cell), an exclusive scan over the buckets, positions handed out bucket by bucket.  The order inside a cell is
 // whatever the atomics make it; no result depends on it (a node's walks and colour are its own).
-RT_D uint32_t node_cell(const GridP &g, const SOrigin &nd) {
+// parts: a cell is cut into parts^3 buckets (the host picks what the bucket array affords)
+RT_D uint32_t node_cell(const GridP &g, const SOrigin &nd, int parts) {
   int i, j, k;
-  if (nd.tri < 0 || !voxel_of(g, ld3(nd.p), i, j, k)) return (uint32_t)g.ncells;  // no hit (or a hit point outside the grid): the last bucket
-  return (uint32_t)cell_index(g, i, j, k);
+  if (nd.tri < 0 || !voxel_of(g, ld3(nd.p), i, j, k)) return (uint32_t)g.ncells * (uint32_t)(parts * parts * parts);  // no hit (or a hit point outside the grid): the last bucket
+  // the part of the cell, from the fraction of the same quotient that gave the cell (any rounding only moves a node to a neighbouring bucket)
+  const float fx = (nd.p[0] - g.dmin[0]) / g.cs[0] - (float)i, fy = (nd.p[1] - g.dmin[1]) / g.cs[1] - (float)j, fz = (nd.p[2] - g.dmin[2]) / g.cs[2] - (float)k;
+  const int si = min(max((int)(fx * parts), 0), parts - 1), sj = min(max((int)(fy * parts), 0), parts - 1), sk = min(max((int)(fz * parts), 0), parts - 1);
+  return (uint32_t)cell_index(g, i, j, k) * (uint32_t)(parts * parts * parts) + (uint32_t)((si * parts + sj) * parts + sk);
 }
 // adds one per active lane to bucket[key], one atomic per distinct key of the wavefront; returns the lane's position
 RT_D uint32_t bucket_take(uint32_t *bucket, uint32_t key, bool active, int lane) {
@@ -1426,21 +1430,24 @@ RT_D uint32_t bucket_take(uint32_t *bucket, uint32_t key, bool active, int lane)
   return pos;
 }
 __global__ void __launch_bounds__(256) k_order_count(GridP g, const SOrigin *__restrict__ sorg, const Ctl *__restrict__ ctl, int level,
-                                                     int node_base, uint32_t *__restrict__ bucket) {
+                                                     int node_base, int parts, uint32_t *__restrict__ bucket) {
   const int n = queue_len(ctl, level), lane = lane_id();
   for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
     const int i = i0 + threadIdx.x;
     const bool valid = i < n;
-    const uint32_t key = valid ? node_cell(g, sorg[node_base + i]) : 0u;
+    const uint32_t key = valid ? node_cell(g, sorg[node_base + i], parts) : 0u;
     (void)bucket_take(bucket, key, valid, lane);
   }
 }
-// exclusive scan of bucket[0 .. nb-1] in place, one block
-__global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ bucket, int nb) {
+// Exclusive scan of bucket[0 .. nb-1] in place, in two launches: every block scans its kScanTile buckets and leaves
+// their sum in totals[block]; one block then scans the totals.  k_order_place adds a bucket's block total to its start.
+constexpr int kScanTile = 4096;
+__global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ bucket, int nb, uint32_t *__restrict__ totals) {
   __shared__ uint32_t part[1024];
-  const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
-  uint32_t sum = 0;
-  for (int q = lo; q < hi; q++) sum += bucket[q];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  uint32_t v[4], sum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { v[q] = base + q < nb ? bucket[base + q] : 0u; sum += v[q]; }
   part[threadIdx.x] = sum;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -1450,17 +1457,39 @@ __global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ buck
     __syncthreads();
   }
   uint32_t run = part[threadIdx.x] - sum;
-  for (int q = lo; q < hi; q++) { const uint32_t v = bucket[q]; bucket[q] = run; run += v; }
+#pragma unroll
+  for (int q = 0; q < 4; q++) { if (base + q < nb) bucket[base + q] = run; run += v[q]; }
+  if (threadIdx.x == 1023) totals[blockIdx.x] = part[1023];
+}
+__global__ void __launch_bounds__(1024) k_order_scan_totals(uint32_t *__restrict__ totals, int n) {
+  __shared__ uint32_t part[1024];
+  uint32_t carry = 0;
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    const int t = t0 + threadIdx.x;
+    const uint32_t v = t < n ? totals[t] : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (t < n) totals[t] = carry + part[threadIdx.x] - v;
+    carry += part[1023];
+    __syncthreads();
+  }
 }
 __global__ void __launch_bounds__(256) k_order_place(GridP g, const SOrigin *__restrict__ sorg, const Ctl *__restrict__ ctl, int level,
-                                                     int node_base, uint32_t *__restrict__ bucket, uint32_t *__restrict__ order) {
+                                                     int node_base, int parts, uint32_t *__restrict__ bucket, const uint32_t *__restrict__ totals,
+                                                     uint32_t *__restrict__ order) {
   const int n = queue_len(ctl, level), lane = lane_id();
   for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
     const int i = i0 + threadIdx.x;
     const bool valid = i < n;
-    const uint32_t key = valid ? node_cell(g, sorg[node_base + i]) : 0u;
+    const uint32_t key = valid ? node_cell(g, sorg[node_base + i], parts) : 0u;
     const uint32_t pos = bucket_take(bucket, key, valid, lane);
-    if (valid) order[node_base + pos] = (uint32_t)i;
+    if (valid) order[node_base + pos + totals[key / kScanTile]] = (uint32_t)i;
   }
 }
 

@@ -66,7 +66,7 @@ struct rtgpu_ctx {
   BatchHdr *d_hdrs = nullptr;
   size_t cap_hdrs = 0;
   TriRec *d_recs = nullptr, *d_recs_unsorted = nullptr;
-  size_t cap_cells = 0, cap_refs = 0, cap_rand = 0;
+  size_t cap_cells = 0, cap_refs = 0, cap_rand = 0, cap_bucket = 0;
   float lmax = 0.0f;         // longest triangle edge of the uploaded scene
   int64_t known_nrefs = -1;  // reference count of the uploaded scene's grid (it does not depend on the camera)
   int64_t known_nonempty = 0;  // and its number of non-empty cells
@@ -122,6 +122,7 @@ struct rtgpu_ctx {
   int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
   uint32_t *d_order = nullptr;  // per level below 0: its nodes by the cell of their hit point (k_order_place)
   int opt_order = 1;  // option "order": 0 queue order everywhere, 1 the levels below 0 by cell, 2 level 0 too
+  int opt_order_parts = 8;  // option "order_parts": the cells are cut into this many parts per axis for the order (1, 2, 4 or 8)
   Ctl *d_ctl = nullptr;
   unsigned char *scratch = nullptr;  // this device's copy of the static scratch array (rtgpu_render_static)
   unsigned long long *d_totals = nullptr;  // [kStatCount + kMaxLevels + 1]
@@ -237,6 +238,14 @@ void glibc_rand_stream(std::vector<int32_t> &out, size_t n) {
   }
 }
 
+// The order of a level's shadow work (k_order_*): parts per cell and axis that keep the bucket array within 2^25 entries,
+// and the buckets that makes (node_cell's keys).
+int order_parts_of(int ncells, int most) {
+  int parts = most;
+  while (parts > 1 && (double)ncells * parts * parts * parts > (double)(1 << 25)) parts >>= 1;
+  return parts;
+}
+size_t order_buckets_of(int ncells, int parts) { return (size_t)ncells * (size_t)(parts * parts * parts) + 1; }
 int64_t tiles_x_of(const rtgpu_ctx *c) { return (c->cam.sw + kTile - 1) / kTile; }
 int64_t tiles_y_of(const rtgpu_ctx *c) { return (c->cam.sh + kTile - 1) / kTile; }
 int64_t tiles_of_rank(int64_t ntiles, int rank, int world) { return rank < ntiles ? (ntiles - rank + world - 1) / world : 0; }
@@ -465,6 +474,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "filter")) c->filter = value != 0;
   else if (!strcmp(name, "record_test")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "record_test: -1 (by the scene), 0 or 1"); c->opt_record_test = (int)value; }
   else if (!strcmp(name, "order")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "order: 0, 1 or 2"); if ((int)value != c->opt_order) c->chunk_tiles_cap = 0; c->opt_order = (int)value; }
+  else if (!strcmp(name, "order_parts")) { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RTGPU_E_INVALID_PARAM, "order_parts: 1, 2, 4 or 8"); c->opt_order_parts = (int)value; }
   else if (!strcmp(name, "split_kernels")) c->opt_split_kernels = (int)value;
   else if (!strcmp(name, "split")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, RTGPU_E_INVALID_PARAM, "split: 0, 1, 2 or 4"); c->opt_split = (int)value; }
   else if (!strcmp(name, "queue_margin")) { if (value < 1 || value > 100000) return fail(c, RTGPU_E_INVALID_PARAM, "queue_margin out of range"); c->queue_margin_permille = (int)value; }
@@ -599,10 +609,17 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     if ((rc = dev_alloc(c, &c->d_counts, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_cell_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->d_nbatch, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->d_hdr_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->d_occ, (size_t)ncells / 32 + 1 + 8)) ||  // + the box of the non-empty cells
-        (rc = dev_alloc(c, &c->d_bucket, (size_t)ncells + 2)) ||
         (rc = dev_alloc(c, &c->alt.d_cell_start, (size_t)ncells + 1)) || (rc = dev_alloc(c, &c->alt.d_hdr_start, (size_t)ncells + 1)) ||
         (rc = dev_alloc(c, &c->alt.d_occ, (size_t)ncells / 32 + 1 + 8))) return rc;
     c->cap_cells = (size_t)ncells + 1;
+  }
+  {  // the buckets of the shading order, then their scan blocks' totals (only where some level is shaded in that order)
+    const bool ordered = c->shade.nslots > 0 && (c->opt_order > 1 || (c->opt_order == 1 && c->levels > 1));
+    const size_t want = ordered ? order_buckets_of(ncells, order_parts_of(ncells, 8)) * (kScanTile + 1) / kScanTile + 2 : 0;
+    if (want > c->cap_bucket) {
+      if ((rc = dev_alloc(c, &c->d_bucket, want))) return rc;
+      c->cap_bucket = want;
+    }
   }
   // The set-up of this frame goes into the set the previous frame does not use, on the build stream: it overlaps
   // the previous frame's kernels (their tail, a few slow wavefronts, leaves most of the GPU idle).
@@ -815,6 +832,9 @@ int chunk_ranks(rtgpu_ctx *c, int n0, const int32_t *sizes, int64_t per_rank, in
 // The order in which level L's nodes are shaded (option "order"), or null: queue order.
 const uint32_t *level_order(const rtgpu_ctx *c, int L) {
   if (c->shade.nslots <= 0 || c->opt_order == 0 || (L == 0 && c->opt_order < 2)) return nullptr;
+  // (the buckets are set up by rtgpu_frame_begin for the options in force then: an order asked for later starts with the next frame)
+  const size_t need = order_buckets_of(c->grid.ncells, order_parts_of(c->grid.ncells, c->opt_order_parts)) * (kScanTile + 1) / kScanTile + 2;
+  if (!c->d_bucket || c->cap_bucket < need || !c->d_order) return nullptr;
   return c->d_order;
 }
 
@@ -838,10 +858,14 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       const uint32_t *order = level_order(c, L);
       if (order) {  // this level's nodes by the cell of their hit point
         const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-        HIPCHK(c, hipMemsetAsync(c->d_bucket, 0, sizeof(uint32_t) * ((size_t)c->grid.ncells + 2), c->stream));
-        KLAUNCH(c, k_order_count, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->d_sorg, (const Ctl *)c->d_ctl, L, (int)c->base[L], c->d_bucket);
-        KLAUNCH(c, k_order_scan, dim3(1), dim3(1024), c->stream, c->d_bucket, c->grid.ncells + 1);
-        KLAUNCH(c, k_order_place, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->d_sorg, (const Ctl *)c->d_ctl, L, (int)c->base[L], c->d_bucket, c->d_order);
+        const int parts = order_parts_of(c->grid.ncells, c->opt_order_parts);
+        const int nbuckets = (int)order_buckets_of(c->grid.ncells, parts), nscan = (nbuckets + kScanTile - 1) / kScanTile;
+        uint32_t *totals = c->d_bucket + nbuckets;
+        HIPCHK(c, hipMemsetAsync(c->d_bucket, 0, sizeof(uint32_t) * (size_t)nbuckets, c->stream));
+        KLAUNCH(c, k_order_count, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->d_sorg, (const Ctl *)c->d_ctl, L, (int)c->base[L], parts, c->d_bucket);
+        KLAUNCH(c, k_order_scan, dim3(nscan), dim3(1024), c->stream, c->d_bucket, nbuckets, totals);
+        KLAUNCH(c, k_order_scan_totals, dim3(1), dim3(1024), c->stream, totals, nscan);
+        KLAUNCH(c, k_order_place, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->d_sorg, (const Ctl *)c->d_ctl, L, (int)c->base[L], parts, c->d_bucket, (const uint32_t *)totals, c->d_order);
       }
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
