@@ -101,9 +101,11 @@ RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, fl
 
 // The rays a wavefront walks through one cell, as a bundle around the leader's ray (direction axis, moment
 // m = o x axis, odr = o.axis): every ray of the group has |r - axis| <= rho, |o - o_leader| <= ro, |o| <= onorm
-// and a parameter range that ends before tmax.
-struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax; };
-RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, float tmax, int leader) {
+// and a parameter range that ends before tmax.  Rays that end somewhere (shadow rays, at their lights; tend = the
+// ray's own last parameter) also have end points o + tend r within re of the leader's, whose range is [0, T]: the
+// bundle of a point light's shadow rays narrows towards the light.  Rays without an end: re = T = infinity.
+struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax, re, T; };
+RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, float tmax, float tend, int leader) {
   Bundle b;
   b.axis = lane_bcast3(r, leader);
   b.m = lane_bcast3(pm, leader);
@@ -122,6 +124,16 @@ RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, floa
   b.ro = wave_max(ro);
   b.onorm = wave_max(on);
   b.tmax = wave_max(tm);
+  b.re = INFINITY; b.T = INFINITY;
+  if (tend < INFINITY) {  // (wave-uniform by construction: a walk kernel's rays all end, or none does)
+    // end points in float: off the line's own point at tend by at most 3 eps (|o| + tend), covered by 2e-6 (onorm + tend)
+    const f3 e = mk3(__builtin_fmaf(tend, r.x, o.x), __builtin_fmaf(tend, r.y, o.y), __builtin_fmaf(tend, r.z, o.z));
+    const f3 de = sub3(e, lane_bcast3(e, leader));
+    float re = in ? __builtin_fmaf(__builtin_amdgcn_sqrtf(dot3(de, de)), 1.001f, 2e-6f * (onorm + tend)) : 0.0f;
+    if (!(re >= 0.0f)) re = INFINITY;
+    b.re = wave_max(re);
+    b.T = lane_bcast(tend, leader);
+  }
   return b;
 }
 
@@ -184,8 +196,8 @@ RT_D void batch_cos(uint32_t count, float *hs, int lane, const Bundle &bu) {
 // rounding).  A NaN compares false: not culled.
 // Two levels.  box_test_bundle: the ray is a bundle's leader and the answer is for every ray of the bundle at once
 // (onorm, tmax: the bundle's maxima).  A point of such a ray at parameter t is within ro + |t| rho of the leader's
-// point at t, and |t| <= tv + |h| + 2 W where the ray meets the widened box, so the extents grow by that much more;
-// tv by ro.  It hands back W before that growth and delta: tv and onorm there are upper bounds of every ray's own,
+// point at t, and |t| <= tv + |h| + 2 W where the ray meets the widened box, so the extents grow by that much more
+// (or, for rays that end, by what the narrowing bundle allows at the box: see there); tv by ro.  It hands back W before that growth and delta: tv and onorm there are upper bounds of every ray's own,
 // so these two serve any single ray of the bundle.  box_test_ray: one ray against the box widened by them (the
 // walk kernels keep c, -+delta, h + W, W in their LDS copy of the header; delta's sign bit marks a batch with a
 // transparent triangle).
@@ -208,17 +220,45 @@ RT_D bool box_separated(const BoxRay &b, f3 r, f3 hw, float W, float delta, floa
   return (__builtin_fabsf(b.ex) > sx) | (__builtin_fabsf(b.ey) > sy) | (__builtin_fabsf(b.ez) > sz) | (b.tc + hr < 0.0f) | (b.tc - hr > tmax);
 }
 RT_D bool box_test_bundle(f3 c, float radius, f3 h, bool transparent, float inv_cos, float ga, float gb, float slack, const Bundle &bu,
-                          bool transparent_counts_anywhere, float &w_ray, float &delta, float &tv) {
+                          bool transparent_counts_anywhere, float &w_ray, float &delta, float &spread) {
   const BoxRay b = box_ray(c, bu.axis, bu.m, bu.odr);
   const float d2 = __builtin_fmaf(b.ex, b.ex, __builtin_fmaf(b.ey, b.ey, b.ez * b.ez));
   const float on5 = 0.00001f * bu.onorm;
-  tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(b.tc, b.tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
+  float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(b.tc, b.tc, d2)), 1.001f, on5 + radius);  // |o - c|^2 = d2 + tc^2
   tv = __builtin_fmaf(bu.ro, 1.001f, tv);  // >= |o - v| for every ray origin o of the bundle and every vertex v of the batch
   delta = __builtin_fmaf(0.00001f, tv, on5 + on5);
   w_ray = __builtin_fmaf(__builtin_fmaf(gb, tv, ga), inv_cos, delta) + slack;
-  const float W = w_ray + __builtin_fmaf(bu.rho, tv + (h.x + h.y + h.z) + (w_ray + w_ray), bu.ro) * 1.001f;
+  const float reach = (h.x + h.y + h.z) + (w_ray + w_ray);  // >= the box's extent along any direction, margins included
+  float widen = __builtin_fmaf(bu.rho, tv + reach, bu.ro);
   // shadow walk: a transparent triangle attenuates wherever it is hit (d >= 0); an opaque one matters only before tmax
-  const float tmax = (transparent_counts_anywhere & transparent) ? INFINITY : bu.tmax;
+  const bool endless = transparent_counts_anywhere & transparent;
+  const float tmax = endless ? INFINITY : bu.tmax;
+  {
+    // Rays that end: the point of a ray at the fraction s >= 0 of its range is within w(s) = |1 - s| ro + s re of the
+    // leader's point at the same fraction, whose parameter s T lies within reach + w(s) of tc.  With far = max(ro, re)
+    // (>= w(s) up to the end) that puts s between (tc - reach - far) / (T + 2 far) and (tc + reach + far) / (T - 2 far),
+    // and w is convex: its largest value over the box is the one at the box's near or far side.  A hit counts up to the
+    // ray's end (s <= 1), a transparent triangle's in the shadow walk beyond it too.
+    // (A hit the exact test reports inside the range may lie up to w_ray outside it: that moves s by w_ray / T,
+    // which adds at most w_ray (ro + re) / T <= w_ray.)  Only for 4 far <= T; a NaN leaves the other bound in force.
+    const float far = __builtin_fmaxf(bu.ro, bu.re);
+    const float s0 = __builtin_fmaxf(b.tc - reach - far, 0.0f) / __builtin_fmaf(2.0f, far, bu.T) * 0.9998f;
+    float s1 = __builtin_fmaxf(b.tc + reach + far, 0.0f) / __builtin_fmaf(-2.0f, far, bu.T) * 1.0002f;
+    if (!endless) s1 = __builtin_fminf(s1, 1.0f);
+    const float sn = __builtin_fminf(s0, s1);
+    const float near_side = __builtin_fmaf(__builtin_fabsf(1.0f - sn), bu.ro, sn * bu.re);
+    const float far_side = __builtin_fmaf(__builtin_fabsf(1.0f - s1), bu.ro, s1 * bu.re);
+    const float narrowing = __builtin_fmaxf(near_side, far_side) * 1.0001f + w_ray;
+    if (4.0f * far <= bu.T) widen = __builtin_fminf(widen, narrowing);
+  }
+  const float W = w_ray + widen * 1.001f;
+  // the spread of the bundle's lines at the batch, for the record-level test (bundle_slabs_pass): with o_L or the leader's
+  // end point e_L as the point the moments are taken about; tb >= |e_L - v| like tv >= |o - v|, |e_L - c|^2 = d2 + (T - tc)^2
+  {
+    const float te = bu.T - b.tc;
+    const float tb = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(te, te, d2)), 1.001f, on5 + radius);
+    spread = __builtin_fminf(__builtin_fmaf(tv, bu.rho, 1.000001f * bu.ro), __builtin_fmaf(tb, bu.rho, 1.000001f * bu.re));
+  }
   return !box_separated(b, bu.axis, mk3(h.x + W, h.y + W, h.z + W), W, delta, tmax);
 }
 RT_D bool box_test_ray(f3 c, float delta_and_flag, f3 hw, float W, f3 r, f3 m, float odr, float tmax_opaque, bool transparent_counts_anywhere) {
@@ -343,12 +383,15 @@ RT_D RecB rec_b(const float *R) {
 // + 28 eps L^2, plus what the computed values are off by, at most 31 eps L (|o| + A) + 5 eps L^2, stays below k1 |o| + k2 = 144
 // eps L (|o| + A) + 56 eps L^2).  A ray of the bundle has r = axis + dr, |dr| <= rho, o = o_L + do, |do| <= ro, so against
 // the leader's values  |det* - det_L*| <= rho |N|,  |tp* - tp_L*| = |do.(r x ik) + (o_L - i).(dr x ik)| <= E = (1.000001 ro + tv rho) L
-// (tv >= |o_L - i| from box_test_bundle; L = |ik|, the longest edge), the same for vp with |ij| <= L, hence
+// (tv >= |o_L - i| from box_test_bundle; L = |ik|, the longest edge).  The moment of a line can be taken about any of its
+// points: for rays that end, about the end points e = o + tend r, which are within re of the leader's: E = (1.000001 re +
+// tb rho) L as well, tb >= |e_L - i|; spread = the smaller of the two brackets, from box_test_bundle.  The same for vp
+// with |ij| <= L, hence
 // |X1* - X1_L*|, |X2* - X2_L*| <= 2 E + rho |N| and |X3* - X3_L*| <= 4 E + rho |N|.  The leader's computed X', det' are
 // within kc_L / 4 of X_L*, det_L*.  So no ray of the bundle can satisfy the acceptance conditions if for one of the three
 //     |X'| > (|det'| + rho |N|) 1.00001 + D + 2 kc_max,      kc_max = k1 onorm_max + k2 (+ slack: infinite when the filter is off)
 // (2 kc_max covers kc / 4 + kc / 4 (1 + 7 eps) + kc of the ray itself); E and the norms are rounded up by 0.1 %.  A NaN compares false.
-RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float tv, const Bundle &bu) {
+RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float spread, const Bundle &bu) {
   const float det = __builtin_fmaf(bu.axis.x, A.n.x, __builtin_fmaf(bu.axis.y, A.n.y, bu.axis.z * A.n.z));
   const float rq = __builtin_fmaf(bu.axis.x, A.q.x, __builtin_fmaf(bu.axis.y, A.q.y, bu.axis.z * A.q.z));
   const float tp = __builtin_fmaf(bu.m.x, A.ac.x, __builtin_fmaf(bu.m.y, A.ac.y, __builtin_fmaf(bu.m.z, A.ac.z, -rq)));
@@ -360,7 +403,7 @@ RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float tv, 
   const float nN = __builtin_amdgcn_sqrtf(__builtin_fmaf(A.n.x, A.n.x, __builtin_fmaf(A.n.y, A.n.y, A.n.z * A.n.z))) * 1.001f;
   const float L = __builtin_amdgcn_sqrtf(__builtin_fmaf(A.ac.x, A.ac.x, __builtin_fmaf(A.ac.y, A.ac.y, A.ac.z * A.ac.z))) * 1.002f;  // (|ij| <= |ik| up to rounding)
   const float rn = bu.rho * nN;
-  const float E2 = (2.0f * L) * __builtin_fmaf(tv, bu.rho, 1.000001f * bu.ro) * 1.001f;  // 2 E
+  const float E2 = (2.0f * L) * spread * 1.001f;  // 2 E
   const float T = __builtin_fmaf(__builtin_fabsf(det) + rn, 1.00001f, rn + (kc_max + kc_max));
   return !((__builtin_fmaxf(__builtin_fabsf(x1), __builtin_fabsf(x2)) > T + E2) | (__builtin_fabsf(x3) > T + (E2 + E2)));
 }
@@ -409,13 +452,13 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     if (lane < nh) {
       float *H = hs + lane * kHdrFloats;
       const v4f hc = *reinterpret_cast<const v4f *>(H), hh = *reinterpret_cast<const v4f *>(H + 4), k = *reinterpret_cast<const v4f *>(H + 8);
-      float w_ray, delta, tv;
+      float w_ray, delta, spread;
       maybe = box_test_bundle(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle,
-                              transparent_counts_anywhere, w_ray, delta, tv);
+                              transparent_counts_anywhere, w_ray, delta, spread);
       if (maybe) {
         H[3] = k.y < 0.0f ? -delta : delta;
         *reinterpret_cast<v4f *>(H + 4) = v4f{hh.x + w_ray, hh.y + w_ray, hh.z + w_ray, w_ray};
-        H[10] = tv;  // (ga, gb have done their work: the slot keeps the bundle's distance bound for the record-level test)
+        H[10] = spread;  // (ga, gb have done their work: the slot keeps the spread of the bundle's lines at the batch for the record-level test)
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1241,7 +1284,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, leader), false, own_sub, own_mask, ph,
+        stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, INFINITY, leader), false, own_sub, own_mask, ph,
                     [&](f3 c, float delta, f3 hw, float W) {
                       return wave_mask(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
@@ -1808,7 +1851,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, leader), true, own_sub, own_mask, ph,
+          stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, dmax, leader), true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
                         return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },

@@ -614,7 +614,7 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
     c->cap_cells = (size_t)ncells + 1;
   }
   {  // the buckets of the shading order, then their scan blocks' totals (only where some level is shaded in that order)
-    const bool ordered = c->shade.nslots > 0 && (c->opt_order > 1 || (c->opt_order == 1 && c->levels > 1));
+    const bool ordered = c->nl + kPlanarSamples * c->npl > 0 && (c->opt_order > 1 || (c->opt_order == 1 && c->levels > 1));
     const size_t want = ordered ? order_buckets_of(ncells, order_parts_of(ncells, 8)) * (kScanTile + 1) / kScanTile + 2 : 0;
     if (want > c->cap_bucket) {
       if ((rc = dev_alloc(c, &c->d_bucket, want))) return rc;

@@ -159,12 +159,15 @@ def _box_separated(e, r, hw, W, delta, tmax):
     return (np.abs(ex) > sx) | (np.abs(ey) > sy) | (np.abs(ez) > sz) | (tc + hr < 0) | (tc - hr > tmax)
 
 
-def bundle_box_may_hit(H, inv_cos, axis, ml, odl, onorm, tmax, ro, rho):
+def bundle_box_may_hit(H, inv_cos, axis, ml, odl, onorm, tmax, ro, rho, re=None, T=None, endless=False):
     """box_test_bundle of rt_kernels.h, operation by operation in float32: the leader's ray (axis, ml, odl) for every
-    ray within ro, rho of it.  Returns (may hit, W for a single ray of the bundle, delta, tv = the bundle's bound of the
-    distance from a ray origin to a vertex of the batch)."""
+    ray within ro, rho of it; re, T: for rays that end, the spread of the end points and the leader's last parameter
+    (None: rays without an end); endless: hits beyond a ray's end count too (transparent triangles in the shadow walk).  Returns (may hit, W for a single ray of the bundle, delta, spread = the spread of the
+    bundle's lines at the batch for the record-level test)."""
     c, h = H["c"], H["h"]
     k = lambda x: np.full_like(onorm, F(x))
+    if re is None:
+        re, T = np.full_like(onorm, F(np.inf)), np.full_like(onorm, F(np.inf))
     with np.errstate(all="ignore"):
         e = _box_ray(c, axis, ml, odl)
         ex, ey, ez, tc = e
@@ -174,15 +177,30 @@ def bundle_box_may_hit(H, inv_cos, axis, ml, odl, onorm, tmax, ro, rho):
         tv = fma(ro, k(1.001), tv)
         delta = fma(k(0.00001), tv, on5 + on5)
         w_ray = fma(fma(H["gb"], tv, H["ga"]), inv_cos, delta)
-        W = w_ray + fma(rho, tv + (h[:, 0] + h[:, 1] + h[:, 2]) + (w_ray + w_ray), ro) * F(1.001)
+        reach = (h[:, 0] + h[:, 1] + h[:, 2]) + (w_ray + w_ray)
+        widen = fma(rho, tv + reach, ro)
+        far = np.maximum(ro, re)
+        s0 = np.maximum(tc - reach - far, F(0)) / fma(k(2), far, T) * F(0.9998)
+        s1 = np.maximum(tc + reach + far, F(0)) / fma(k(-2), far, T) * F(1.0002)
+        if not endless:
+            s1 = np.minimum(s1, F(1))
+        sn = np.minimum(s0, s1)
+        near_side = fma(np.abs(F(1) - sn), ro, sn * re)
+        far_side = fma(np.abs(F(1) - s1), ro, s1 * re)
+        narrowing = np.maximum(near_side, far_side) * F(1.0001) + w_ray
+        widen = np.where(F(4) * far <= T, np.fmin(widen, narrowing), widen)
+        W = w_ray + widen * F(1.001)
+        te = T - tc
+        tb = fma(np.sqrt(fma(te, te, d2)), k(1.001), on5 + H["radius"])
+        spread = np.fmin(fma(tv, rho, F(1.000001) * ro), fma(tb, rho, F(1.000001) * re))
         out = _box_separated(e, axis, (h[:, 0] + W, h[:, 1] + W, h[:, 2] + W), W, delta, tmax)
-    return ~out, w_ray, delta, tv
+    return ~out, w_ray, delta, spread
 
 
-def bundle_slabs_pass(T, kc_max, tv, axis, ml, ro, rho):
+def bundle_slabs_pass(T, kc_max, spread, axis, ml, rho):
     """bundle_slabs_pass of rt_kernels.h, operation by operation in float32: may any ray of the bundle pass the record's three slabs?"""
     N, ac, Q, ab, P = T["N"], T["ac"], T["Q"], T["ab"], T["P"]
-    k = lambda x: np.full_like(tv, F(x))
+    k = lambda x: np.full_like(spread, F(x))
     with np.errstate(all="ignore"):
         det = fma(axis[:, 0], N[:, 0], fma(axis[:, 1], N[:, 1], axis[:, 2] * N[:, 2]))
         rq = fma(axis[:, 0], Q[:, 0], fma(axis[:, 1], Q[:, 1], axis[:, 2] * Q[:, 2]))
@@ -195,7 +213,7 @@ def bundle_slabs_pass(T, kc_max, tv, axis, ml, ro, rho):
         nN = np.sqrt(fma(N[:, 0], N[:, 0], fma(N[:, 1], N[:, 1], N[:, 2] * N[:, 2]))) * F(1.001)
         L = np.sqrt(fma(ac[:, 0], ac[:, 0], fma(ac[:, 1], ac[:, 1], ac[:, 2] * ac[:, 2]))) * F(1.002)
         rn = rho * nN
-        E2 = (F(2.0) * L) * fma(tv, rho, F(1.000001) * ro) * F(1.001)
+        E2 = (F(2.0) * L) * spread * F(1.001)
         Tt = fma(np.abs(det) + rn, k(1.00001), rn + (kc_max + kc_max))
         return ~((np.maximum(np.abs(x1), np.abs(x2)) > Tt + E2) | (np.abs(x3) > Tt + (E2 + E2)))
 
@@ -320,13 +338,23 @@ def test_filter_never_contradicts_the_exact_test(scale, offset, aim):
         for bound, which, what in ((np.full(n, np.inf, F), acc, "an accepted hit"), (best, acc & (d < best), "a nearer hit"),
                                    (dmax, blocker, "a blocker")):
             tb = np.maximum(bound, bound[::-1])  # the bundle's bound is the largest of its rays'
-            may, w_ray, delta, tv = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, tb, ro, rho)
+            may, w_ray, delta, spread = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, tb, ro, rho)
             assert may[which].all(), "bundle test culled " + what
             # ... and with the bundle's W and delta this ray's own test must not cull it either
             assert ray_box_may_hit(H, w_ray, delta, r, m, odr, bound)[which].all(), "ray test with the bundle's margins culled " + what
+            if bound is dmax:
+                # rays that end (shadow rays): this ray at o + dmax r, the leader, with a range of its own, at ol + Tl axis
+                with np.errstate(all="ignore"):
+                    Tl = (dmax * rng.uniform(0.7, 1.4, n).astype(F)).astype(F)
+                    de = (o + dmax[:, None] * r) - (ol + Tl[:, None] * axis)
+                    re = (np.sqrt(dot32(de, de)) * F(1.001) + F(2e-6) * (onb + np.maximum(dmax, Tl))).astype(F)
+                may, w_ray, delta, spread_e = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, np.maximum(tb, Tl), ro, rho, re, Tl)
+                assert may[which].all(), "bundle test of ending rays culled " + what
+                kc_max = fma(T["k1"], onb, np.abs(T["k2"]))
+                assert bundle_slabs_pass(T, kc_max, spread_e, axis, ml, rho)[acc].all(), "slab test of ending rays dropped a triangle one of them hits"
         # the record-level test of the bundle: a triangle that this ray of the bundle hits is never dropped for the bundle
         kc_max = fma(T["k1"], onb, np.abs(T["k2"]))
-        slab = bundle_slabs_pass(T, kc_max, tv, axis, ml, ro, rho)
+        slab = bundle_slabs_pass(T, kc_max, spread, axis, ml, rho)
         assert slab[acc].all(), "the bundle's slab test dropped a triangle one of its rays hits"
         slab_stats.append((slab[~acc].mean(), float(np.median(rho))))
     fuzz = batch_cos(H, r, np.full(n, F(1e-7), F))
@@ -384,3 +412,53 @@ def test_nan_rays_and_triangles_are_never_rejected():
         kc = fma(T["k1"], onorm, T["k2"])
         p1, p2, inside, sure, sd, ad = stages(T, o, r, m, kc)
     assert p1.all() and p2.all() and not inside.any() and not sure.any()
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.05, 20.0), (10.0, -200.0)])
+def test_bundles_of_rays_that_end_at_one_point(scale, offset):
+    """Shadow rays of a point light: two rays from neighbouring origins to the same point (the light, beyond, on or
+    before the triangle) as a bundle that narrows towards it.  A blocker of the second ray (an accepted hit inside
+    (1e-5, dmax)) is never culled by the leader's box test nor dropped by the record-level test."""
+    rng = np.random.default_rng(int(scale * 1000) + 7)
+    n = 300000
+    a, ab, ac, o, r0 = make_cases(rng, n, scale, offset, aim_edges)
+    # the light: on the first ray, at 0.3 .. 3 times the distance of the aimed-at point
+    d0 = np.linalg.norm((a - o).astype(np.float64), axis=1) + 1e-30
+    light = (o.astype(np.float64) + r0.astype(np.float64) * (d0 * 10.0 ** rng.uniform(-0.5, 0.5, n))[:, None]).astype(F)
+
+    def shadow_ray(org):
+        rr = (light - org).astype(F)
+        s2 = rr[:, 0] * rr[:, 0] + rr[:, 1] * rr[:, 1] + rr[:, 2] * rr[:, 2]
+        inv = (1.0 / np.sqrt(s2.astype(np.float64))).astype(F)
+        return rr * inv[:, None], np.sqrt(s2.astype(np.float64)).astype(F)   # direction, dmax as dist3 gives it
+
+    r, dmax = shadow_ray(o)
+    ol = (o + (rng.standard_normal((n, 3)) * scale * 10.0 ** rng.uniform(-3, 0, (n, 1))).astype(F)).astype(F)
+    axis, Tl = shadow_ray(ol)
+    acc, acc_uv, d, u, v, det = exact_test(a, ab, ac, o, r)
+    blocker = acc & (d > F(0.00001)) & (d < dmax)
+    assert blocker.mean() > 0.05
+    T = preprocess(a, ab, ac)
+    m, onorm, odr = ray_side(o, r)
+    ml, onl, odl = ray_side(ol, axis)
+    H = batch_header(T)
+    dlt, dorg = r - axis, o - ol
+    rho = (np.sqrt(dot32(dlt, dlt)) * F(1.001) + F(1e-7)).astype(F)
+    ro = (np.sqrt(dot32(dorg, dorg)) * F(1.001)).astype(F)
+    onb = np.maximum(onorm, onl)
+    inv_cos = batch_cos(H, axis, rho)
+    de = (o + dmax[:, None] * r) - (ol + Tl[:, None] * axis)
+    re = (np.sqrt(dot32(de, de)) * F(1.001) + F(2e-6) * (onb + np.maximum(dmax, Tl))).astype(F)
+    assert np.median(re / np.maximum(ro, F(1e-30))) < 0.2   # the bundles do narrow (re is the float slack of the end points)
+    may, w_ray, delta, spread = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, np.maximum(dmax, Tl), ro, rho, re, Tl)
+    assert may[blocker].all(), "the narrowing bundle's box test culled a blocker"
+    assert ray_box_may_hit(H, w_ray, delta, r, m, odr, dmax)[blocker].all()
+    kc_max = fma(T["k1"], onb, np.abs(T["k2"]))
+    assert bundle_slabs_pass(T, kc_max, spread, axis, ml, rho)[acc].all(), "the record-level test dropped a triangle the second ray hits"
+    # a transparent triangle attenuates wherever the ray meets it, beyond the light too
+    may_e, w_e, delta_e, _ = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, np.full(n, np.inf, F), ro, rho, re, Tl, endless=True)
+    assert may_e[acc].all(), "the bundle's box test culled an accepted hit beyond or before the light"
+    assert ray_box_may_hit(H, w_e, delta_e, r, m, odr, np.full(n, np.inf, F))[acc].all()
+    # and the narrowing model culls more than the widening one
+    may_wide, _, _, _ = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, np.maximum(dmax, Tl), ro, rho)
+    assert may.sum() <= may_wide.sum()
