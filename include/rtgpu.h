@@ -151,9 +151,10 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * of the grid cells their hit points lie in, so that a wavefront's 64 shadow rays start close together; 0: in queue order;
  * 2: the first level too; same image), "order_parts" (default 8: that order distinguishes this many parts of a cell along each
  * axis, as far as 2^25 buckets allow; 1, 2, 4 or 8),
- * "record_test" (default -1: by the scene; 1 / 0: the walk kernels test the records of a batch against the whole bundle of a
- * wavefront's rays before they stage the batch, or do not: same image either way; it pays where bundles are narrow against
- * the triangles, and -1 switches it on unless half of the scene's triangles or more are transparent),
+ * "record_test" (default 1; 1 / 0: the walk kernels test the records of a batch against the whole bundle of a wavefront's rays
+ * before they stage the batch, or do not; -1: only unless half of the scene's triangles or more are transparent; same image),
+ * "bundle_ends" (default -1: in scenes with reflective or transparent surfaces; 1 / 0: the shadow walk's culling knows, or does
+ * not, that a wavefront's shadow rays end at their lights and come closer together on the way; same image),
  * "filter" (default 1; 0 switches off the conservative triangle filter and the batch culling of the
  * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */
 int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);

@@ -220,7 +220,7 @@ RT_D bool box_separated(const BoxRay &b, f3 r, f3 hw, float W, float delta, floa
   return (__builtin_fabsf(b.ex) > sx) | (__builtin_fabsf(b.ey) > sy) | (__builtin_fabsf(b.ez) > sz) | (b.tc + hr < 0.0f) | (b.tc - hr > tmax);
 }
 RT_D bool box_test_bundle(f3 c, float radius, f3 h, bool transparent, float inv_cos, float ga, float gb, float slack, const Bundle &bu,
-                          bool transparent_counts_anywhere, float &w_ray, float &delta, float &spread) {
+                          bool transparent_counts_anywhere, bool ends, float &w_ray, float &delta, float &spread) {
   const BoxRay b = box_ray(c, bu.axis, bu.m, bu.odr);
   const float d2 = __builtin_fmaf(b.ex, b.ex, __builtin_fmaf(b.ey, b.ey, b.ez * b.ez));
   const float on5 = 0.00001f * bu.onorm;
@@ -233,7 +233,8 @@ RT_D bool box_test_bundle(f3 c, float radius, f3 h, bool transparent, float inv_
   // shadow walk: a transparent triangle attenuates wherever it is hit (d >= 0); an opaque one matters only before tmax
   const bool endless = transparent_counts_anywhere & transparent;
   const float tmax = endless ? INFINITY : bu.tmax;
-  {
+  spread = __builtin_fmaf(tv, bu.rho, 1.000001f * bu.ro);  // the spread of the bundle's lines at the batch, for the record-level test (bundle_slabs_pass)
+  if (ends) {
     // Rays that end: the point of a ray at the fraction s >= 0 of its range is within w(s) = |1 - s| ro + s re of the
     // leader's point at the same fraction, whose parameter s T lies within reach + w(s) of tc.  With far = max(ro, re)
     // (>= w(s) up to the end) that puts s between (tc - reach - far) / (T + 2 far) and (tc + reach + far) / (T - 2 far),
@@ -250,15 +251,13 @@ RT_D bool box_test_bundle(f3 c, float radius, f3 h, bool transparent, float inv_
     const float far_side = __builtin_fmaf(__builtin_fabsf(1.0f - s1), bu.ro, s1 * bu.re);
     const float narrowing = __builtin_fmaxf(near_side, far_side) * 1.0001f + w_ray;
     if (4.0f * far <= bu.T) widen = __builtin_fminf(widen, narrowing);
-  }
-  const float W = w_ray + widen * 1.001f;
-  // the spread of the bundle's lines at the batch, for the record-level test (bundle_slabs_pass): with o_L or the leader's
-  // end point e_L as the point the moments are taken about; tb >= |e_L - v| like tv >= |o - v|, |e_L - c|^2 = d2 + (T - tc)^2
-  {
+    // ... and the lines' spread with the leader's end point e_L as the point the moments are taken about:
+    // tb >= |e_L - v| like tv >= |o - v|, |e_L - c|^2 = d2 + (T - tc)^2
     const float te = bu.T - b.tc;
     const float tb = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(te, te, d2)), 1.001f, on5 + radius);
-    spread = __builtin_fminf(__builtin_fmaf(tv, bu.rho, 1.000001f * bu.ro), __builtin_fmaf(tb, bu.rho, 1.000001f * bu.re));
+    spread = __builtin_fminf(spread, __builtin_fmaf(tb, bu.rho, 1.000001f * bu.re));
   }
+  const float W = w_ray + widen * 1.001f;
   return !box_separated(b, bu.axis, mk3(h.x + W, h.y + W, h.z + W), W, delta, tmax);
 }
 RT_D bool box_test_ray(f3 c, float delta_and_flag, f3 hw, float W, f3 r, f3 m, float odr, float tmax_opaque, bool transparent_counts_anywhere) {
@@ -420,9 +419,10 @@ RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float spre
 //                      records at a time before f; also for the statistics of diagnostic builds.
 // RECTEST: with the record-level test of the bundle (bundle_slabs_pass) between the ray-by-ray test of the boxes and the
 // staging; without it every record of a kept batch is tested.  It pays where bundles are narrow against the triangles.
+// ENDS: the bundle's rays end (Bundle.re, .T are set) and the bundle test uses that.
 // own_sub, own_mask: for a ticket shared by own_mask + 1 wavefronts, only the header chunks (256 records) whose index
 // & own_mask equals own_sub are looked at (0, 0: all of them).
-template <bool RECTEST, typename C, typename T, typename B, typename P, typename F, typename G>
+template <bool RECTEST, bool ENDS, typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
                       bool transparent_counts_anywhere, uint32_t own_sub, uint32_t own_mask, Phases &ph, C &&cull, T &&tally, B &&batch,
                       P &&pass1, F &&f, G &&more) {
@@ -454,7 +454,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       const v4f hc = *reinterpret_cast<const v4f *>(H), hh = *reinterpret_cast<const v4f *>(H + 4), k = *reinterpret_cast<const v4f *>(H + 8);
       float w_ray, delta, spread;
       maybe = box_test_bundle(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle,
-                              transparent_counts_anywhere, w_ray, delta, spread);
+                              transparent_counts_anywhere, ENDS, w_ray, delta, spread);
       if (maybe) {
         H[3] = k.y < 0.0f ? -delta : delta;
         *reinterpret_cast<v4f *>(H + 4) = v4f{hh.x + w_ray, hh.y + w_ray, hh.z + w_ray, w_ray};
@@ -1284,7 +1284,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, INFINITY, leader), false, own_sub, own_mask, ph,
+        stream_cell<RECTEST, false>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, INFINITY, leader), false, own_sub, own_mask, ph,
                     [&](f3 c, float delta, f3 hw, float W) {
                       return wave_mask(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
@@ -1710,7 +1710,9 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 // transparency product ts (>= 0) if the light is visible, -1 if the point is in shadow, stored slot-major too
 // (ts_out[slot * ts_stride + node]: one full line per ticket).
 // The reference's per-triangle shadow cache (voxelize.c:647-655) is scan-order state; it is dropped.
-template <bool COUNT, bool RECTEST>
+// ENDS: the bundle of a visit knows that its rays end at their lights (Bundle.re, .T): sharper culling where the rays of
+// a ticket start far apart and meet at the light; where they start on one 8x8 tile it costs more than it saves.
+template <bool COUNT, bool RECTEST, bool ENDS>
 __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const SOrigin *__restrict__ sorg,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
                                                 long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base, SplitP split,
@@ -1851,7 +1853,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell<RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, dmax, leader), true, own_sub, own_mask, ph,
+          stream_cell<RECTEST, ENDS>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, leader), true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
                         return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },

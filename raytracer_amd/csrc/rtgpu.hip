@@ -114,7 +114,8 @@ struct rtgpu_ctx {
   unsigned long long *d_split_keys = nullptr, *d_split_masks = nullptr;
   uint32_t *d_split_done_n = nullptr, *d_split_done_s = nullptr;
   int opt_split_kernels = 3;  // option "split_kernels": bit 0 nearest walk, bit 1 shadow walk (diagnostic)
-  int opt_record_test = -1;  // option "record_test": the bundle's record-level test in the walk kernels; -1: where most of the scene is opaque
+  int opt_record_test = 1;  // option "record_test": the bundle's record-level test in the walk kernels
+  int opt_bundle_ends = -1;  // option "bundle_ends": the shadow walk's bundles narrow towards their lights; -1: in scenes with secondary rays
   bool mostly_opaque = true;  // fewer than half of the scene's triangles are transparent (kt > 0)
   int opt_split = 0;  // option "split": 0 never, 1 as the queue length suggests, 2 / 4: every ticket, that many ways
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
@@ -473,6 +474,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
   else if (!strcmp(name, "record_test")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "record_test: -1 (by the scene), 0 or 1"); c->opt_record_test = (int)value; }
+  else if (!strcmp(name, "bundle_ends")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "bundle_ends: -1 (by the scene), 0 or 1"); c->opt_bundle_ends = (int)value; }
   else if (!strcmp(name, "order")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "order: 0, 1 or 2"); if ((int)value != c->opt_order) c->chunk_tiles_cap = 0; c->opt_order = (int)value; }
   else if (!strcmp(name, "order_parts")) { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RTGPU_E_INVALID_PARAM, "order_parts: 1, 2, 4 or 8"); c->opt_order_parts = (int)value; }
   else if (!strcmp(name, "split_kernels")) c->opt_split_kernels = (int)value;
@@ -869,10 +871,13 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       }
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
-#define RT_LAUNCH_SHADOW(COUNT, RECTEST) \
-  KLAUNCH(c, (k_shadow<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split, order)
-      if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW(true, true); else RT_LAUNCH_SHADOW(true, false); }
-      else { if (rectest) RT_LAUNCH_SHADOW(false, true); else RT_LAUNCH_SHADOW(false, false); }
+#define RT_LAUNCH_SHADOW(COUNT, RECTEST, ENDS) \
+  KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split, order)
+#define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)
+      const bool ends = c->opt_bundle_ends < 0 ? c->levels > 1 : c->opt_bundle_ends != 0;
+      if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW2(true, true); else RT_LAUNCH_SHADOW2(true, false); }
+      else { if (rectest) RT_LAUNCH_SHADOW2(false, true); else RT_LAUNCH_SHADOW2(false, false); }
+#undef RT_LAUNCH_SHADOW2
 #undef RT_LAUNCH_SHADOW
     }
   }

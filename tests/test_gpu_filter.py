@@ -65,17 +65,19 @@ def test_filter_on_and_off_give_the_same_frame(renderer, prefix, over, w, h, tex
 @pytest.mark.parametrize("prefix,over,w,h,tex", CASES, ids=[c[0].split("/")[1] + ("_glass" if c[1] and "pokoj" in str(c[1]) else "") + "_%dx%d" % (c[2], c[3]) for c in CASES])
 def test_record_level_bundle_test_does_not_change_the_frame(renderer, prefix, over, w, h, tex):
     """Option "record_test": the walk kernels drop, before a batch is staged, the records no ray of the wavefront's bundle
-    can pass (1), or test every record of a kept batch (0); -1 chooses by the scene.  Same frame, bit for bit, and the
-    same algorithmic counters."""
+    can pass (1), or test every record of a kept batch (0); -1 chooses by the scene; option "bundle_ends": the shadow walk's
+    culling uses that its rays end at their lights.  Same frame, bit for bit, and the same algorithmic counters."""
     over = {k: os.path.join(ROOT, v) for k, v in over.items()}
     scene = rt.Scene(os.path.join(ROOT, prefix), texture=tex, width=w, height=h, **over)
     frames = []
     try:
-        for mode in (1, 0, -1):
+        for mode, ends in ((1, 0), (0, 0), (-1, -1), (1, 1), (0, 1)):
             renderer.set_option("record_test", mode)
+            renderer.set_option("bundle_ends", ends)  # the shadow walk's bundles narrow towards their lights, or are not told so
             frames.append(frame(renderer, scene, 1, count=True))
     finally:
-        renderer.set_option("record_test", -1)
+        renderer.set_option("record_test", 1)
+        renderer.set_option("bundle_ends", -1)
     (a, ca) = frames[0]
     for b, cb in frames[1:]:
         assert np.array_equal(a["ids"], b["ids"])
