@@ -137,37 +137,33 @@ RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, floa
   return b;
 }
 
-// For the batches of one header chunk and the rays of one bundle: an upper bound of 1 / |cos(ray, normal)|
-// over the batch's triangles, written into the LDS copy of each batch's header.  |cos| >= |axis.n| - rho for
-// the unit normal n, and the header's 10-bit normal is within 0.0017 of n.  A triangle the bundle may be coplanar with
-// (bound below 1e-3, or below a quarter of the batch's gb) makes the batch's value infinite: that batch is not culled in
-// this visit.  One lane per record, 64 records (8 headers) per pass; count = the chunk's records.
+// For a batch of a cell's list and the rays of one bundle: an upper bound of 1 / |cos(ray, normal)| over the batch's
+// triangles.  |cos| >= |axis.n| - rho for the unit normal n, and the header's 10-bit normal is within 0.0017 of n.  A
+// triangle the bundle may be coplanar with (bound below 1e-3, or below a quarter of the batch's gb) makes the batch's
+// value infinite: that batch is not culled in this visit.  The lane that tests the batch's box works it out.
 RT_D uint32_t pack_normal(float x, float y, float z) {  // (a NaN or infinite component: the zero vector, no bound)
   if (!(__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z) < 2.0f)) return 0u;
   const int qx = (int)rintf(x * 511.0f), qy = (int)rintf(y * 511.0f), qz = (int)rintf(z * 511.0f);
   return (uint32_t)(qx & 0x3ff) | (uint32_t)(qy & 0x3ff) << 10 | (uint32_t)(qz & 0x3ff) << 20;
 }
-RT_D void batch_cos(uint32_t count, float *hs, int lane, const Bundle &bu) {
-  static_assert(kBatch == 8, "a batch is half a DPP row of 16 lanes");
-  const float sx = bu.axis.x * (1.0f / 511.0f), sy = bu.axis.y * (1.0f / 511.0f), sz = bu.axis.z * (1.0f / 511.0f);
-  for (uint32_t p0 = 0; p0 < count; p0 += 64) {
-    const uint32_t p = p0 + (uint32_t)lane;
-    float *H = hs + (p / kBatch) * kHdrFloats;
-    float c0 = INFINITY;  // lanes past the end of the list do not count
-    if (p < count) {
-      const uint32_t w = __float_as_uint(H[12 + (lane & (kBatch - 1))]);
-      const float nx = (float)((int)(w << 22) >> 22), ny = (float)((int)(w << 12) >> 22), nz = (float)((int)(w << 2) >> 22);
-      c0 = __builtin_fabsf(sx * nx + sy * ny + sz * nz);
-      if (!(c0 >= 0.0f)) c0 = 0.0f;  // a NaN must not be dropped by the min below
-    }
-    c0 = row_minmax16<false, kBatch>(c0);
-    const float cosb = c0 * 0.9999f - 0.0018f - bu.rho;
-    if ((lane & (kBatch - 1)) == kBatch - 1 && p - (kBatch - 1) < count) {  // the last lane of a batch holds its minimum
-      const float least = __builtin_fmaxf(0.001f, 0.25f * H[11]);  // gb / 4: below it det may change its sign by rounding
-      H[7] = cosb > least ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
-    }
+// The bound for one batch, from the eight packed normals of its header (records: how many of them are there).
+RT_D float batch_cos(const float *H, int records, float gb, const Bundle &bu) {
+  const float q = 1.0f / 511.0f;
+  const float sx = bu.axis.x * q, sy = bu.axis.y * q, sz = bu.axis.z * q;
+  const v4f a = *reinterpret_cast<const v4f *>(H + 12), b = *reinterpret_cast<const v4f *>(H + 16);
+  const float words[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  float c0 = INFINITY;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t w = __float_as_uint(words[j]);
+    const float nx = (float)((int)(w << 22) >> 22), ny = (float)((int)(w << 12) >> 22), nz = (float)((int)(w << 2) >> 22);
+    float c = __builtin_fabsf(sx * nx + sy * ny + sz * nz);
+    if (!(c >= 0.0f)) c = 0.0f;  // a NaN must not be dropped by the min
+    if (j < records) c0 = __builtin_fminf(c0, c);
   }
-  __builtin_amdgcn_wave_barrier();
+  const float cosb = c0 * 0.9999f - 0.0018f - bu.rho;
+  const float least = __builtin_fmaxf(0.001f, 0.25f * gb);  // gb / 4: below it det may change its sign by rounding
+  return cosb > least ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
 }
 
 // Can the exact test report a hit of the ray (r, m = o x r, odr = o.r, |o| <= onorm) with a triangle of the
@@ -440,11 +436,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     if (lane < kHdrVecs * nh) glds16(hsrc + kHdrVecs * h0 + lane, hs);
     if (lane + 64 < kHdrVecs * nh) glds16(hsrc + kHdrVecs * h0 + lane + 64, hs + 256);
     if (lane + 128 < kHdrVecs * nh) glds16(hsrc + kHdrVecs * h0 + lane + 128, hs + 512);
-    {
-      const uint32_t left = cnt - h0 * kBatch;
-      wait_staged();
-      batch_cos(left < (uint32_t)(kHdrChunk * kBatch) ? left : (uint32_t)(kHdrChunk * kBatch), hs, lane, bundle);
-    }
+    wait_staged();
     ph.template end<2>();
     // one lane per batch: can any ray of the bundle meet the batch's box at all?  If so the lane rewrites its header
     // for the ray-by-ray test: c, -+delta, h + W, W (box_test_ray)
@@ -453,7 +445,9 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       float *H = hs + lane * kHdrFloats;
       const v4f hc = *reinterpret_cast<const v4f *>(H), hh = *reinterpret_cast<const v4f *>(H + 4), k = *reinterpret_cast<const v4f *>(H + 8);
       float w_ray, delta, spread;
-      maybe = box_test_bundle(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, hh.w, k.z, k.w, g.slack, bundle,
+      const uint32_t left = cnt - (h0 + (uint32_t)lane) * kBatch;
+      const float inv_cos = batch_cos(H, left < (uint32_t)kBatch ? (int)left : kBatch, k.w, bundle);
+      maybe = box_test_bundle(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, inv_cos, k.z, k.w, g.slack, bundle,
                               transparent_counts_anywhere, ENDS, w_ray, delta, spread);
       if (maybe) {
         H[3] = k.y < 0.0f ? -delta : delta;
