@@ -140,27 +140,32 @@ RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, floa
 // For a batch of a cell's list and the rays of one bundle: an upper bound of 1 / |cos(ray, normal)| over the batch's
 // triangles.  |cos| >= |axis.n| - rho for the unit normal n, and the header's 10-bit normal is within 0.0017 of n.  A
 // triangle the bundle may be coplanar with (bound below 1e-3, or below a quarter of the batch's gb) makes the batch's
-// value infinite: that batch is not culled in this visit.  The lane that tests the batch's box works it out.
+// value infinite: that batch is not culled in this visit.  Two lanes per batch work it out, four normals each (lane b and
+// lane b + 32), before lane b tests the batch's box.
 RT_D uint32_t pack_normal(float x, float y, float z) {  // (a NaN or infinite component: the zero vector, no bound)
   if (!(__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z) < 2.0f)) return 0u;
   const int qx = (int)rintf(x * 511.0f), qy = (int)rintf(y * 511.0f), qz = (int)rintf(z * 511.0f);
   return (uint32_t)(qx & 0x3ff) | (uint32_t)(qy & 0x3ff) << 10 | (uint32_t)(qz & 0x3ff) << 20;
 }
-// The bound for one batch, from the eight packed normals of its header (records: how many of them are there).
-RT_D float batch_cos(const float *H, int records, float gb, const Bundle &bu) {
+// Smallest |axis.n| over four of the eight packed normals of a batch's header (the ones from `from`; records: how many
+// of the batch's eight are there), and the bound for the batch from the smallest over all eight.
+RT_D float batch_cos_part(const float *H, int from, int records, const Bundle &bu) {
   const float q = 1.0f / 511.0f;
   const float sx = bu.axis.x * q, sy = bu.axis.y * q, sz = bu.axis.z * q;
-  const v4f a = *reinterpret_cast<const v4f *>(H + 12), b = *reinterpret_cast<const v4f *>(H + 16);
-  const float words[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const v4f a = *reinterpret_cast<const v4f *>(H + 12 + from);
+  const float words[4] = {a.x, a.y, a.z, a.w};
   float c0 = INFINITY;
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
+  for (int j = 0; j < 4; j++) {
     const uint32_t w = __float_as_uint(words[j]);
     const float nx = (float)((int)(w << 22) >> 22), ny = (float)((int)(w << 12) >> 22), nz = (float)((int)(w << 2) >> 22);
     float c = __builtin_fabsf(sx * nx + sy * ny + sz * nz);
     if (!(c >= 0.0f)) c = 0.0f;  // a NaN must not be dropped by the min
-    if (j < records) c0 = __builtin_fminf(c0, c);
+    if (from + j < records) c0 = __builtin_fminf(c0, c);
   }
+  return c0;
+}
+RT_D float batch_inv_cos(float c0, float gb, const Bundle &bu) {
   const float cosb = c0 * 0.9999f - 0.0018f - bu.rho;
   const float least = __builtin_fmaxf(0.001f, 0.25f * gb);  // gb / 4: below it det may change its sign by rounding
   return cosb > least ? __builtin_amdgcn_rcpf(cosb) * 1.01f : INFINITY;
@@ -441,13 +446,22 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     ph.template end<2>();
     // one lane per batch: can any ray of the bundle meet the batch's box at all?  If so the lane rewrites its header
     // for the ray-by-ray test: c, -+delta, h + W, W (box_test_ray)
+    static_assert(kHdrChunk == 32, "two lanes per batch of a chunk");
+    float c0 = INFINITY;
+    {
+      const int b = lane & 31;
+      if (b < nh) {
+        const uint32_t left = cnt - (h0 + (uint32_t)b) * kBatch;
+        c0 = batch_cos_part(hs + b * kHdrFloats, lane < 32 ? 0 : 4, left < (uint32_t)kBatch ? (int)left : kBatch, bundle);
+      }
+      c0 = __builtin_fminf(c0, __shfl_xor(c0, 32));
+    }
     bool maybe = false;
     if (lane < nh) {
       float *H = hs + lane * kHdrFloats;
       const v4f hc = *reinterpret_cast<const v4f *>(H), hh = *reinterpret_cast<const v4f *>(H + 4), k = *reinterpret_cast<const v4f *>(H + 8);
       float w_ray, delta, spread;
-      const uint32_t left = cnt - (h0 + (uint32_t)lane) * kBatch;
-      const float inv_cos = batch_cos(H, left < (uint32_t)kBatch ? (int)left : kBatch, k.w, bundle);
+      const float inv_cos = batch_inv_cos(c0, k.w, bundle);
       maybe = box_test_bundle(mk3(hc.x, hc.y, hc.z), hc.w, mk3(hh.x, hh.y, hh.z), k.y < 0.0f, inv_cos, k.z, k.w, g.slack, bundle,
                               transparent_counts_anywhere, ENDS, w_ray, delta, spread);
       if (maybe) {
