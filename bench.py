@@ -9,7 +9,10 @@ rtVisualizedSceneToBitmap do: per-triangle preprocess, grid build, primary rays,
 shading with one shadow query per (hit, light), global min/max, tone map to RGBA8, and with N>1 the
 min/max all-reduce and the RGBA8 tile gather to rank 0 (RCCL).  The scene is uploaded to HBM before
 the timed region; the finished image stays in HBM on rank 0.  The frame is split by 8x8 tiles over
-the ranks, so total work is fixed as N grows ("strong" scaling).
+the ranks, so total work is fixed as N grows ("strong" scaling).  With N > 1 two frames are in flight on every GPU
+(raytracer_amd.dist.FramePipeline: each in its own context and stream; a frame's exchange and the latency-bound end of
+its walk kernels run under the next frame's kernels); all K frames are complete when the timed region ends, and
+ms_per_step is the region's length / K.  config.frames_in_flight says how many; --frames-in-flight overrides.
 
 metric = Mrays/s, rays counted as the reference issues them (nearest-hit queries + shadow queries,
 back-face early-outs included): 40,689,192 per temple 4K frame.
@@ -190,6 +193,7 @@ def main():
     ap.add_argument("--scene", default="temple")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 1 on one GPU, 2 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-width", type=int, default=960)
     ap.add_argument("--cpu-height", type=int, default=540)
@@ -211,7 +215,7 @@ def main():
     import torch
     import torch.distributed as dist
     import raytracer_amd as rt
-    from raytracer_amd.dist import FrameRenderer
+    from raytracer_amd.dist import FramePipeline, default_depth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -232,12 +236,15 @@ def main():
     prefix, over = scenes[args.scene]
     prefix = os.path.join(ROOT, prefix)
     scene = rt.Scene(prefix, width=args.width, height=args.height, **over)
-    renderer = rt.Renderer(local_rank)
+    # Frames in flight on this rank's GPU (FramePipeline): one on a single GPU, two where a rank renders a share of the frame
+    depth = args.frames_in_flight if args.frames_in_flight > 0 else default_depth(world)
+    pipe = FramePipeline(lambda: rt.Renderer(local_rank), scene, rank, world, depth)
+    renderer = pipe.renderers[0]
 
     # untimed counting pass: rays per frame, S and T per kernel family for the roofline (this rank's tiles)
     renderer.set_option("count", 1)
-    fr = FrameRenderer(renderer, scene, rank, world)
-    fr.frame()
+    with torch.cuda.stream(pipe.streams[0]):
+        pipe.slots[0].frame()
     torch.cuda.synchronize(dev)
     cnt = renderer.counters().asdict()
     renderer.set_option("count", 0)
@@ -248,16 +255,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        fr.frame()
+    for _ in range(max(args.warmup, depth if depth > 1 else 0)):
+        pipe.frame()
     barrier()
     renderer.timings()  # drop what warm-up accumulated
+    pipe.issued = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        fr.frame()
+        pipe.frame()
     barrier()
     elapsed = time.perf_counter() - t0
     tim = renderer.timings().asdict()
+    timed_frames = (args.steps + depth - 1) // depth  # frames of the timed region that ran in slot 0, whose kernels are timed
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rays_t = torch.tensor([cnt["nearest_queries"] + cnt["shadow_queries"]], dtype=torch.float64, device=dev)
@@ -277,7 +286,7 @@ def main():
             q, S, T = cnt["shadow_queries"], cnt["shadow_steps"], cnt["shadow_tests"]
         else:
             q, S, T = cnt["nearest_queries"], cnt["nearest_steps"], cnt["nearest_tests"]
-        per_launch = args.steps / launches  # frames per launch of this family (1 when the frame is one chunk)
+        per_launch = timed_frames / launches  # frames per launch of this family (1 when the frame is one chunk)
         full = cnt[fam + "_full_tests"]
         workload = "%s %dx%d" % (args.scene, args.width, args.height)
         roof = roofline(fam, avg_ms, q * per_launch, S * per_launch, T * per_launch, full * per_launch,
@@ -291,10 +300,13 @@ def main():
             "config": {"workload": "scenes/%s %dx%d, depth 5, %d point lights, frame = preprocess + grid build + trace + "
                                    "shade + tone map%s" % (args.scene, args.width, args.height, scene.nl,
                                                             " + RCCL min/max all-reduce + RGBA8 tile gather" if world > 1 else ""),
-                       "rays_per_frame": int(rays_frame), "tiling": "8x8 tiles round-robin over %d rank(s)" % world},
-            "kernel_ms_per_frame_rank0": {k: round(v / args.steps, 3) for k, v in tim.items() if k.endswith("_ms")},
+                       "rays_per_frame": int(rays_frame), "tiling": "8x8 tiles round-robin over %d rank(s)" % world,
+                       "frames_in_flight": depth},
+            "kernel_ms_per_frame_rank0": {k: round(v / timed_frames, 3) for k, v in tim.items() if k.endswith("_ms")},
             "kernel_ms_note": "HIP events on the stream each kernel runs on; preprocess_ms and grid_ms are elapsed on the build "
-                              "stream, where the set-up of frame k+1 overlaps the walk kernels of frame k (alone it takes 0.27 ms)",
+                              "stream, where the set-up of frame k+1 overlaps the walk kernels of frame k (alone it takes 0.27 ms)"
+                              + ("; with %d frames in flight a kernel shares the GPU with the other frame's, so these are longer than "
+                                 "the kernel alone" % depth if depth > 1 else ""),
             "roofline": roof,
         }
         def ratio(a, b):

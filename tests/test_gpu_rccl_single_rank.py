@@ -37,6 +37,15 @@ for prefix, w, h in (("scenes/s3/s3", 96, 72), ("scenes/s2/s2", 64, 48), ("scene
     want = r2.tonemap_host(g["rgb"], g["minmax"], scene.gamma)
     assert np.array_equal(got, want), prefix
     assert np.array_equal(fr.global_minmax.cpu().numpy(), g["minmax"]), prefix
+    # the same frames two deep: each slot of the pipeline has its own context and stream, the collectives of one frame are
+    # issued between the kernels of the other
+    pipe = D.FramePipeline(lambda: rt.Renderer(0), scene, 0, 1, depth=2)
+    imgs = [pipe.frame() for _ in range(5)]
+    pipe.finish()
+    torch.cuda.synchronize()
+    for img, _ in imgs[-2:]:
+        assert np.array_equal(img.cpu().numpy().view(np.uint32).reshape(h, w), want), prefix
+    pipe.close()
     r.close(); r2.close()
 dist.destroy_process_group()
 print("rccl single rank ok")
