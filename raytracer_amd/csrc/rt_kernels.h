@@ -99,6 +99,26 @@ RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, fl
 #endif
 }
 
+// The lane a visit's bundle is described about: the spreads about a ray in the middle of the group are about half of
+// those about a ray at its rim (temple 4K: shadow walk 4.37 -> 4.21 ms).  tile: the wavefront's rays are the pixels of an
+// 8x8 tile or the shadow rays of their hit points (lane = 8 y + x): the lane of the group nearest the tile's middle.
+// Otherwise the rays come in queue order (secondary rays, nodes ordered by the cell of their hit point), in which
+// neighbours lie close together: the lane of the group nearest the middle of the wavefront.
+#ifndef RT_CENTRAL
+#define RT_CENTRAL 1
+#endif
+RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
+#if RT_CENTRAL
+  const int x2 = 2 * (lane & 7) - 7, y2 = 2 * (lane >> 3) - 7, l2 = 2 * lane - 63;
+  const int off = tile ? x2 * x2 + y2 * y2 : (l2 < 0 ? -l2 : l2);
+  const float key = in ? (float)(off * 64 + lane) : INFINITY;  // (an integer below 2^13: exact)
+  const float least = -wave_max(-key);
+  return least < INFINITY ? ((int)least & 63) : fallback;
+#else
+  return fallback;
+#endif
+}
+
 // The rays a wavefront walks through one cell, as a bundle around the leader's ray (direction axis, moment
 // m = o x axis, odr = o.axis): every ray of the group has |r - axis| <= rho, |o - o_leader| <= ro, |o| <= onorm
 // and a parameter range that ends before tmax.  Rays that end somewhere (shadow rays, at their lights; tend = the
@@ -278,6 +298,8 @@ __device__ unsigned long long g_phase[16];
 __device__ unsigned long long g_hist[2][2][9];  // [walk][0 = batches, 1 = (lane, record) pairs][records of the batch some lane passed]
 __device__ unsigned long long g_mode[2][3][4];  // [walk][cell, lane, ray mode][visits, wave-level record tests, lane-level record tests, rays in the group]
 __device__ unsigned long long g_cand[2][4];     // [walk][headers looked at, passed the bundle's box test, kept by the ray-by-ray test, cell visits]
+__device__ unsigned long long g_chunk[2][12];   // [walk][header chunks staged, without a candidate, without a kept batch, without a batch left by the record-level test,
+                                                //        visits and headers of lists of 1, 2, 3-4, 5+ chunks]
 #endif
 // Per-ticket log of the walk kernels, only in builds with -DRT_TICKETS (tools/tickets.py): shader clocks from
 // taking the ticket to its last result, cell visits, batches that reached the ray-by-ray test, records tested.
@@ -494,6 +516,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     }
 #ifdef RT_HIST
     if (lane == 0) atomicAdd(&g_cand[transparent_counts_anywhere ? 1 : 0][2], (unsigned long long)__popcll(kept));
+    const unsigned long long hist_kept_boxes = kept;
 #endif
     // Record by record, for the bundle: the kept batches are numbered in list order (their numbers go through LDS), lane
     // 8 i + j takes record j of kept batch p0 + i and asks whether any ray of the bundle can pass the record's first slab
@@ -529,6 +552,13 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       __builtin_amdgcn_wave_barrier();
       kept = __ballot(lane < kHdrChunk && ((kept_all >> lane) & 1u) && __float_as_uint(hs[lane * kHdrFloats + 11]) != 0u);
     }
+#ifdef RT_HIST
+    if (lane == 0) {
+      unsigned long long *q = g_chunk[transparent_counts_anywhere ? 1 : 0];
+      atomicAdd(&q[0], 1ull); if (candidates == 0) atomicAdd(&q[1], 1ull); if (hist_kept_boxes == 0) atomicAdd(&q[2], 1ull); if (kept == 0) atomicAdd(&q[3], 1ull);
+      if (h0 == 0) { const int cls = nb <= 32 ? 0 : nb <= 64 ? 1 : nb <= 128 ? 2 : 3; atomicAdd(&q[4 + 2 * cls], 1ull); atomicAdd(&q[5 + 2 * cls], (unsigned long long)nb); }
+    }
+#endif
     ph.template end<3>();
     // the kept batches through two LDS buffers: the next one is on its way while this one is tested
     auto first_record = [&](int b) { return beg + (h0 + (uint32_t)b) * kBatch; };
@@ -1289,7 +1319,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell<RECTEST, false, !RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, INFINITY, leader), false, own_sub, own_mask, ph,
+        stream_cell<RECTEST, false, !RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, INFINITY, central_lane(proc, lane, prim.on != 0, leader)), false, own_sub, own_mask, ph,
                     [&](f3 c, float delta, f3 hw, float W) {
                       return wave_mask(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
@@ -1858,7 +1888,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell<RECTEST, ENDS, true>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, leader), true, own_sub, own_mask, ph,
+          stream_cell<RECTEST, ENDS, true>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader)), true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
                         return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },

@@ -1194,6 +1194,7 @@ int rtgpu_debug_hist(rtgpu_ctx *c, unsigned long long *out) {
   HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(unsigned long long) * 36));
   HIPCHK(c, hipMemcpyFromSymbol(out + 36, HIP_SYMBOL(g_cand), sizeof(unsigned long long) * 8));
   HIPCHK(c, hipMemcpyFromSymbol(out + 44, HIP_SYMBOL(g_mode), sizeof(unsigned long long) * 24));
+  HIPCHK(c, hipMemcpyFromSymbol(out + 68, HIP_SYMBOL(g_chunk), sizeof(unsigned long long) * 24));
   return RTGPU_OK;
 }
 #endif

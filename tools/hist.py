@@ -18,7 +18,7 @@ r = rt.Renderer(0)
 r.upload(sc)
 r.set_option("count", 1)  # the per-mode statistics come from the counting variants of the kernels
 r.frame_begin(); r.render_host()
-out = (C.c_ulonglong * 68)()
+out = (C.c_ulonglong * 92)()
 L = rt.gpu_lib()
 L.rtgpu_debug_hist.argtypes = [C.c_void_p, C.c_void_p]
 L.rtgpu_debug_hist(r._h, out)
@@ -39,3 +39,8 @@ for k, name in enumerate(("nearest", "shadow")):
         vis, wv, ln, rays = m[4 * i:4 * i + 4]
         print("  %s mode: %d visits (%.1f rays per visit), %d wave-level record tests (%.1f per visit), lane use %.3f"
               % (mode, vis, rays / max(vis, 1), wv, wv / max(vis, 1), ln / max(64 * wv, 1)))
+    q = v[68 + 12 * k:80 + 12 * k]
+    print("  header chunks staged %d: %.1f %% without a candidate, %.1f %% without a batch kept by the box tests, %.1f %% without a batch left by the record-level test"
+          % (q[0], 100.0 * q[1] / max(q[0], 1), 100.0 * q[2] / max(q[0], 1), 100.0 * q[3] / max(q[0], 1)))
+    for i, cls in enumerate(("1 chunk", "2 chunks", "3-4 chunks", "5+ chunks")):
+        print("  lists of %s: %d cell-mode visits, %d headers" % (cls, q[4 + 2 * i], q[5 + 2 * i]))
