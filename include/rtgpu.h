@@ -116,7 +116,8 @@ typedef struct rtgpu_counters {
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP
- * events recorded around every launch on the context's stream (only with option "timing" = 1). */
+ * events recorded around every launch on the context's stream (only with option "timing" = 1; 2 = around the two
+ * walk kernels only, the other members stay 0: the events of a whole frame cost 0.07 ms of a 5.5 ms frame). */
 typedef struct rtgpu_timings {
   float preprocess_ms, grid_ms, primary_ms, nearest_ms, hit_ms, shadow_ms, accumulate_ms, minmax_ms;
   int32_t nearest_launches, shadow_launches;
@@ -139,7 +140,7 @@ int rtgpu_set_stream(rtgpu_ctx *ctx, void *hip_stream);
  * unless the caller made another one current), which rtgpu_set_stream cannot name because NULL means "own". */
 int rtgpu_set_null_stream(rtgpu_ctx *ctx);
 
-/* Options: "count" (0/1) S/T counters, "timing" (0/1) per-kernel events, "chunk_bytes" (device
+/* Options: "count" (0/1) S/T counters, "timing" (0/1/2) per-kernel events (2: walk kernels only), "chunk_bytes" (device
  * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default:
  * what each walk kernel is compiled for, 20 and 24), "pipeline" (default 1: rtgpu_frame_begin builds on its
  * own stream into the buffers the previous frame does not use, overlapping that frame's kernels; 0: on the context's stream),

@@ -41,7 +41,8 @@ struct rtgpu_ctx {
   int num_cu = 256;
   std::string msg;
   // options
-  bool opt_count = false, opt_timing = false;
+  bool opt_count = false;
+  int opt_timing = 0;  // 0 off, 1 events around every kernel family, 2 around the two walk kernels only
   int64_t chunk_bytes = 8ll << 30;
   int waves_per_cu = 0;  // wavefronts per CU of the persistent walk kernels; 0 = what each is compiled for (its register budget)
   bool opt_pipeline = true;  // frame set-up on its own stream, into the set of buffers the previous frame does not use
@@ -187,15 +188,16 @@ void mark_released(rtgpu_ctx *c) {
 }
 
 struct Span {  // HIP events around launches, on the stream the kernels go to
-  rtgpu_ctx *c; int what; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+  rtgpu_ctx *c; int what; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
   Span(rtgpu_ctx *ctx, int w, hipStream_t stream = nullptr) : c(ctx), what(w), st(stream ? stream : ctx->stream) {
-    if (c->opt_timing) {
+    on = c->opt_timing == 1 || (c->opt_timing == 2 && (w == W_NEAREST || w == W_SHADOW));
+    if (on) {
       (void)hipEventCreate(&a); (void)hipEventCreate(&b);
       (void)hipEventRecord(a, st);
     }
   }
   ~Span() {
-    if (c->opt_timing) { (void)hipEventRecord(b, st); c->spans.push_back({a, b, what}); }
+    if (on) { (void)hipEventRecord(b, st); c->spans.push_back({a, b, what}); }
   }
 };
 
@@ -211,9 +213,8 @@ void resolve_spans(rtgpu_ctx *c) {
     if (s.what == W_SHADOW) ns++;
     (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
   }
-  if (!c->spans.empty()) {
-    c->timings = {acc[W_PRE], acc[W_GRID], acc[W_PRIMARY], acc[W_NEAREST], acc[W_HIT], acc[W_SHADOW], acc[W_ACCUM], acc[W_MINMAX], nn, ns};
-  }
+  // (nothing recorded since the previous call: all zero)
+  c->timings = {acc[W_PRE], acc[W_GRID], acc[W_PRIMARY], acc[W_NEAREST], acc[W_HIT], acc[W_SHADOW], acc[W_ACCUM], acc[W_MINMAX], nn, ns};
   c->spans.clear();
 }
 
@@ -470,7 +471,7 @@ int rtgpu_set_null_stream(rtgpu_ctx *c) {
 int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   if (!c || !name) return RTGPU_E_INVALID_PARAM;
   if (!strcmp(name, "count")) c->opt_count = value != 0;
-  else if (!strcmp(name, "timing")) c->opt_timing = value != 0;
+  else if (!strcmp(name, "timing")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "timing is 0, 1 or 2"); c->opt_timing = (int)value; }
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
   else if (!strcmp(name, "record_test")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "record_test: -1 (by the scene), 0 or 1"); c->opt_record_test = (int)value; }
@@ -1008,8 +1009,8 @@ int rtgpu_render_static(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t
   // Nothing in the array has to start at zero: every queue entry is written by the kernel that produces it before the
   // kernel that consumes it reads it (hits, nodes, ts and colours of shaded hits, one partial range per block of
   // level 0), and the counters live in the context's control block, which k_chunk_init resets.
-  const bool timing = c->opt_timing;
-  c->opt_timing = false;  // (the per-kernel timing creates events: an allocating call)
+  const int timing = c->opt_timing;
+  c->opt_timing = 0;  // (the per-kernel timing creates events: an allocating call)
   c->split_tiles = -1;
   int rc = RTGPU_OK;
   do {
