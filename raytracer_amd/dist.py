@@ -173,8 +173,11 @@ class FrameRenderer:
 
 
 def default_depth(world):
-    """Frames in flight that pay on `world` GPUs: a whole frame fills one GPU by itself (measured: 5.71 against 5.77 ms
-    per frame with two in flight), a share of it does not."""
+    """Frames in flight on `world` GPUs.  A share of a frame leaves most of the machine idle for most of a walk kernel:
+    two in flight (one rank of eight 1.35 -> 1.05 ms per frame; three: 1.14).  A whole 4K frame fills one GPU except at
+    the ends of its two walk kernels; three frames in flight put other frames' kernels there (5.55 -> 5.45 ms per frame;
+    two: 5.55, the two frames fall into step; four: 5.50), but a kernel's launch time then depends on what runs beside
+    it, so one GPU renders one frame at a time unless asked otherwise."""
     return 1 if world <= 1 else 2
 
 
