@@ -708,37 +708,66 @@ RT_D int pick_mode(int group, uint32_t leader_cnt, int short_lanes) {
   return leader_cnt * RT_CELL_COST <= ray_cost ? kCellMode : kRayMode;
 }
 
-// Work distribution of the persistent walk kernels: a ticket is 64 consecutive queue entries, taken from a
-// device-wide counter.  All wavefronts add to the same address, and such atomics are served one after another
-// at the memory side (about 15 ns each, measured: 506 000 tickets took 9 ms whatever the kernels did in between),
-// so a wavefront takes several tickets per atomic when there are many: 1/RT_GRAB_DIV of its fair share, at most
-// RT_GRAB_MAX.  The tickets of one grab lie far apart in the queue (neighbouring tiles cost about the same, and a
-// run of expensive ones in one wavefront would be the last to finish).  The last RT_GRAB_TAIL sixteenths of the
-// queue are handed out one ticket at a time, so that the wavefronts finish together whatever a ticket costs.
+// Work distribution of the persistent walk kernels: a ticket is 64 consecutive queue entries, taken from device-wide
+// counters.  Atomics on one address are served one after another at the memory side (about 15 ns each, measured:
+// 506 000 tickets from one counter took 9 ms whatever the kernels did in between), so a wavefront takes two tickets
+// per atomic when there are many (1/RT_GRAB_DIV of its fair share, at most RT_GRAB_MAX), and the atomics are spread
+// over several counters (below).  The tickets of one grab lie far apart in the queue (neighbouring tiles cost about
+// the same, and a run of expensive ones in one wavefront would be the last to finish).  The last RT_GRAB_TAIL /
+// RT_GRAB_TAIL_DEN of the queue are handed out one ticket at a time, so that the wavefronts finish together whatever
+// a ticket costs.
 #ifndef RT_GRAB_DIV
 #define RT_GRAB_DIV 4
-#define RT_GRAB_MAX 4
+#endif
+#ifndef RT_GRAB_MAX
+#define RT_GRAB_MAX 2
 #endif
 #ifndef RT_GRAB_TAIL
 #define RT_GRAB_TAIL 2
 #endif
+#ifndef RT_GRAB_TAIL_DEN
+#define RT_GRAB_TAIL_DEN 16
+#endif
+// The counters: a walk kernel's slots are dealt out by RT_COUNTERS counters instead of one (counter k hands out the slots
+// k, k + RT_COUNTERS, ...: each walks the whole queue, so the queue is still worked through front to back).  With a
+// single counter the single-ticket tail of a shadow walk (an eighth of 506 000 tickets, 15 ns each: 0.95 ms) took
+// longer to hand out than to work through, and four tickets per atomic were needed before it (temple 4K: shadow
+// walk 4.14 -> 3.70 ms, nearest-hit walk 1.13 -> 1.03 ms with eight counters and two per atomic).  The counters lie 4 KB apart
+// behind the control block (different memory channels).  A wavefront starts with the counter of its block and moves on
+// to the next one when a counter has nothing left; it is done when all have run out.
+#ifndef RT_COUNTERS
+#define RT_COUNTERS 8
+#endif
+constexpr int kCounters = RT_COUNTERS, kCounterStride = 1024, kTicketArea = 4096;  // (words between counters; bytes from the control block to the first)
+constexpr size_t kCtlBytes = kTicketArea + sizeof(uint32_t) * 2 * kMaxLevels * kCounters * kCounterStride;
+RT_D uint32_t *ticket_counters(Ctl *ctl, int which, int level) {  // which: 0 nearest walk, 1 shadow walk
+  return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctl) + kTicketArea) + (size_t)((which * kMaxLevels + level) * kCounters) * kCounterStride;
+}
 struct Tickets {
   uint32_t per_grab, groups, singles, slot = 0, taken;  // slots 0..groups-1: per_grab tickets, `groups` apart; then single tickets
+  uint32_t tried = 0;                                   // counters this wavefront has found empty
   RT_D explicit Tickets(unsigned long long total) {
     const unsigned long long tickets = (total + 63) / 64, waves = (unsigned long long)gridDim.x * (blockDim.x / 64);
     const unsigned long long share = tickets / (waves * RT_GRAB_DIV);
     per_grab = (uint32_t)(share < 1 ? 1 : share > RT_GRAB_MAX ? RT_GRAB_MAX : share);
-    groups = per_grab > 1 ? (uint32_t)(tickets * (16 - RT_GRAB_TAIL) / 16 / per_grab) : 0u;
+    groups = per_grab > 1 ? (uint32_t)(tickets * (RT_GRAB_TAIL_DEN - RT_GRAB_TAIL) / RT_GRAB_TAIL_DEN / per_grab) : 0u;
     singles = (uint32_t)(tickets - (unsigned long long)groups * per_grab);
     taken = per_grab;
   }
   // base of the next ticket of this wavefront, false when nothing is left
-  RT_D bool take(uint32_t *counter, int lane, uint32_t &base) {
+  RT_D bool take(uint32_t *counters, int lane, uint32_t &base) {
     if (taken >= per_grab) {
-      uint32_t s = 0;
-      if (lane == 0) s = atomicAdd(counter, 1u);
-      slot = __builtin_amdgcn_readfirstlane(s);
-      if (slot >= groups + singles) return false;  // the counter only grows
+      for (;;) {
+        if (tried >= (uint32_t)kCounters) return false;
+        const uint32_t k = (blockIdx.x + tried) % (uint32_t)kCounters;
+        uint32_t s = 0;
+        if (lane == 0) s = atomicAdd(counters + k * kCounterStride, 1u);
+        s = __builtin_amdgcn_readfirstlane(s);
+        // (slots are numbered below 2^32 / 64; a counter that has run out is asked at most once more by every wavefront)
+        const unsigned long long global_slot = (unsigned long long)s * kCounters + k;
+        if (global_slot < (unsigned long long)groups + singles) { slot = (uint32_t)global_slot; break; }
+        tried++;  // the counters only grow: this one stays empty
+      }
       taken = slot < groups ? 0u : per_grab - 1u;
     }
     const uint32_t ticket = slot < groups ? slot + taken * groups : groups * per_grab + (slot - groups);
@@ -1190,6 +1219,8 @@ RT_D Ray primary_ray(const PrimaryP &pp, const GridP &g, int idx, bool with_voxe
 __global__ void __launch_bounds__(256) k_chunk_init(int n0, QueueCaps caps, Ctl *__restrict__ ctl) {
   static_assert(sizeof(Ctl) % 4 == 0 && sizeof(Ctl) / 4 <= 256, "one thread per word of the control block");
   if (threadIdx.x < sizeof(Ctl) / 4) reinterpret_cast<uint32_t *>(ctl)[threadIdx.x] = 0u;
+  static_assert(2 * kMaxLevels * kCounters <= 256, "one thread per ticket counter");
+  if (threadIdx.x < 2 * kMaxLevels * kCounters) ticket_counters(ctl, 0, 0)[(size_t)threadIdx.x * kCounterStride] = 0u;
   __syncthreads();
   if (threadIdx.x == 0) ctl->count[0] = n0;
   if (threadIdx.x <= kMaxLevels) ctl->cap[threadIdx.x] = caps.cap[threadIdx.x];
@@ -1236,7 +1267,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
   Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
   for (;;) {
     uint32_t base;
-    if (!tickets.take(&ctl->ticket_nearest[level], lane, base)) break;
+    if (!tickets.take(ticket_counters(ctl, 0, level), lane, base)) break;
     uint32_t own_sub = 0, own_mask = 0, shared = 0;  // shared = index of the ticket among the shared ones
     if ((base >> 6) >= split_from) {
       const uint32_t q = (base >> 6) - split_from;
@@ -1779,7 +1810,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
   for (;;) {
     uint32_t base;
-    if (!tickets.take(&ctl->ticket_shadow[level], lane, base)) break;
+    if (!tickets.take(ticket_counters(ctl, 1, level), lane, base)) break;
     uint32_t own_sub = 0, own_mask = 0, shared = 0;
     if ((base >> 6) >= split_from) {
       const uint32_t q = (base >> 6) - split_from;

@@ -143,13 +143,12 @@ struct ShadeP {
   float total_flux, distmod;
 };
 
-// Device-side control block of one chunk: queue lengths, tickets of the persistent kernels, statistics.
+// Device-side control block of one chunk: queue lengths and statistics (the allocation continues with the ticket counters
+// of the persistent kernels, kCtlBytes in all).
 struct Ctl {
   int32_t count[kMaxLevels + 1];        // rays/nodes per level as produced; what was produced beyond cap[] is dropped
   int32_t cap[kMaxLevels + 1];          // capacity of every level's queue: readers use min(count, cap) (queue_len)
-  uint32_t ticket_nearest[kMaxLevels];
-  uint32_t ticket_shadow[kMaxLevels];
-  uint32_t pad;
+  uint32_t pad[2 * kMaxLevels + 1];     // (the ticket counters of the walk kernels lie behind the block, 4 KB apart: ticket_counters)
   unsigned long long stat[32];
 };
 // Tickets of a walk kernel that are shared by several wavefronts ("ways", a power of two): tickets from..end of the

@@ -417,7 +417,7 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
-  if (hipMalloc((void **)&c->d_ctl, sizeof(Ctl)) != hipSuccess ||
+  if (hipMalloc((void **)&c->d_ctl, kCtlBytes) != hipSuccess ||
       hipMalloc((void **)&c->d_totals, sizeof(unsigned long long) * kTotals) != hipSuccess ||
       hipMalloc((void **)&c->d_partial, sizeof(float) * 6 * kPartialBlocks) != hipSuccess) {
     rtgpu_destroy(c);

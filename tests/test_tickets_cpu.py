@@ -1,10 +1,11 @@
 """The persistent walk kernels' ticket hand-out (struct Tickets in raytracer_amd/csrc/rt_kernels.h), restated:
-whatever the queue length and the number of wavefronts, the slots of the device-wide counter map to every
-ticket exactly once, grouped tickets lie `groups` apart, and the last part of the queue is handed out singly."""
+whatever the queue length and the number of wavefronts, the slots map to every ticket exactly once, grouped
+tickets lie `groups` apart, the last part of the queue is handed out singly, and the counters that deal out the
+slots (counter k: slots k, k + COUNTERS, ...) hand out every slot exactly once in whatever order wavefronts ask them."""
 import numpy as np
 import pytest
 
-GRAB_DIV, GRAB_MAX, GRAB_TAIL = 4, 4, 2  # the defaults of rt_kernels.h
+GRAB_DIV, GRAB_MAX, GRAB_TAIL, COUNTERS = 4, 2, 2, 8  # the defaults of rt_kernels.h
 
 
 def plan(total, waves):
@@ -44,4 +45,33 @@ def test_every_ticket_is_handed_out_exactly_once(total, waves):
 def test_small_queues_are_not_grouped_and_large_ones_keep_a_single_ticket_tail():
     assert plan(16200 * 64, 6144)[1] == 1                      # one rank of eight: two or three tickets per wavefront
     tickets, per_grab, groups, singles = plan(32394792, 6144)  # temple 4K shadow queue
-    assert per_grab == 4 and singles >= tickets // 8 and groups * 4 >= tickets * 3 // 4
+    assert per_grab == GRAB_MAX and singles >= tickets // 8 and groups * per_grab >= tickets * 3 // 4
+
+
+@pytest.mark.parametrize("slots", [0, 1, 7, 8, 9, 1000, 12345])
+@pytest.mark.parametrize("waves", [1, 5, 64])
+def test_the_counters_hand_out_every_slot_once(slots, waves):
+    """Tickets::take: a wavefront asks the counter of its block, takes global slot s * COUNTERS + k for the value s it
+    gets from counter k, and moves on to the next counter (for good) when that slot does not exist."""
+    rng = np.random.default_rng(slots * 131 + waves)
+    counters = [0] * COUNTERS
+    tried = [0] * waves
+    home = [int(rng.integers(0, 1 << 20)) for _ in range(waves)]  # blockIdx.x
+    seen = np.zeros(slots, np.int32)
+    live = list(range(waves))
+    asked = 0
+    while live:
+        w = live[int(rng.integers(0, len(live)))]  # any interleaving of the wavefronts
+        k = (home[w] + tried[w]) % COUNTERS
+        s = counters[k]
+        counters[k] += 1
+        asked += 1
+        g = s * COUNTERS + k
+        if g < slots:
+            seen[g] += 1
+        else:
+            tried[w] += 1
+            if tried[w] >= COUNTERS:
+                live.remove(w)
+    assert (seen == 1).all()
+    assert asked == slots + waves * COUNTERS  # every wavefront finds every counter empty exactly once
