@@ -247,6 +247,13 @@ int rtgpu_phase_cycles(rtgpu_ctx *ctx, int64_t out[16], int reset);
  * the library was built with -DRT_TICKETS (tools/tickets.py). */
 int rtgpu_ticket_log(rtgpu_ctx *ctx, int which, uint32_t *out, int max_tickets, int *copied);
 
+/* Diagnostic, no counterpart in the reference: the reference normalises vectors with `1.0f / sqrt(x)` and measures
+ * distances with `sqrt(x)` on float x, which C evaluates in double and rounds to float once (src/vectormath.h:45-48,
+ * 60-66).  The kernels compute the same floats with fewer double-precision instructions; this call compares the two
+ * forms on the device for all 2^32 float inputs and returns the number of inputs whose results differ
+ * (mismatches[0]: reciprocal square root, mismatches[1]: square root).  Both must be 0.  About 0.1 s. */
+int rtgpu_math_selfcheck(rtgpu_ctx *ctx, uint64_t mismatches[2]);
+
 /* Single-GPU convenience for a C host: frame_begin must have been called; renders all tiles and
  * returns row-major host arrays (rgb w*h*3, ids w*h, minmax 6).  Any output may be NULL. */
 int rtgpu_render_host(rtgpu_ctx *ctx, float *rgb, int32_t *ids, float *minmax);

@@ -778,6 +778,22 @@ struct Tickets {
 };
 
 // ------------------------------------------------------------------------------------------------
+// rsqrt_ref and sqrt_ref (rt_math.h) against the double-precision idioms they stand for, for every one of the 2^32
+// binary32 inputs: bad[0], bad[1] count the inputs whose results differ in any bit (two NaNs count as equal).
+__global__ void __launch_bounds__(256) k_math_selfcheck(unsigned long long *__restrict__ bad) {
+  unsigned long long n0 = 0, n1 = 0;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+    const float s = __uint_as_float((uint32_t)i);
+    const float a = rsqrt_ref(s), b = rsqrt_exact(s), c = sqrt_ref(s), d = sqrt_exact(s);
+    if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) n0++;
+    if (__float_as_uint(c) != __float_as_uint(d) && !(c != c && d != d)) n1++;
+  }
+  for (int off = 32; off > 0; off >>= 1) { n0 += __shfl_down(n0, off); n1 += __shfl_down(n1, off); }
+  if (lane_id() == 0) { atomicAdd(&bad[0], n0); atomicAdd(&bad[1], n1); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-triangle preprocess for one camera (preprocess.c:17-32): ij, ik, unit normal flipped towards
 // the observer, plane offset d.  geom: 9 floats (i, ij, ik); aux: 4 floats (n, d).
 // Also the per-triangle record of the staged filter (rt_math.h), evaluated in double from the float edges

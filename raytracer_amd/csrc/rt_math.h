@@ -30,18 +30,54 @@ RT_D f3 cross3(f3 a, f3 b) {
   return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 // vectormath.h:60-66: `1.0f/sqrt(float)` promotes to double: sqrt and the division are binary64, the
-// quotient is rounded to float once.
+// quotient is rounded to float once.  rsqrt_exact is that chain as written; rsqrt_ref gives the same float for every
+// input with a fifth of the double-precision instructions: y = 1/sqrt(s) from the hardware's estimate and two Newton
+// steps is within 2^-47 of the true value, and so is the chain's double result (two correctly rounded operations), so
+// both round to the same float unless a midpoint between two floats lies within 2^-46 of y: the low 29 bits of y's
+// mantissa then lie within 2^6 of 2^28.  Those inputs (a window of 2^11, four in a million) and everything outside
+// the plain normal range take the chain itself.  rtgpu_math_selfcheck compares the two for all 2^32 inputs.
+RT_D float rsqrt_exact(float s) { return (float)(1.0 / sqrt((double)s)); }
+#ifndef RT_FAST_F64
+#define RT_FAST_F64 1
+#endif
+RT_D float rsqrt_ref(float s) {
+#if RT_FAST_F64
+  if (s > 1e-30f && s < 1e30f) {  // (a NaN fails both)
+    const double x = (double)s;
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const double g = x * y, h = 0.5 * y;
+      y = __builtin_fma(y, __builtin_fma(-g, h, 0.5), y);
+    }
+    const uint32_t low = (uint32_t)(unsigned long long)__double_as_longlong(y) & 0x1fffffffu;
+    if (low - (0x10000000u - 1024u) > 2048u) return (float)y;
+  }
+#endif
+  return rsqrt_exact(s);
+}
 RT_D f3 normalize3(f3 v) {
   float s = v.x * v.x + v.y * v.y + v.z * v.z;
-  float inv = (float)(1.0 / sqrt((double)s));
+  float inv = rsqrt_ref(s);
   return mk3(v.x * inv, v.y * inv, v.z * inv);
 }
 // vectormath.h:122-127: normalised b - a
 RT_D f3 ray3(f3 a, f3 b) { return normalize3(sub3(b, a)); }
-// vectormath.h:45-48: sqrt evaluated in double, result rounded to float
+// vectormath.h:45-48: sqrt evaluated in double, result rounded to float.  For a float argument that is the correctly
+// rounded binary32 square root: rounding a square root first to 53 and then to 24 bits cannot differ from rounding it
+// to 24 bits at once (53 >= 2 x 24 + 2), and the compiler's sqrtf is the correctly rounded one here (also compared for
+// all 2^32 inputs by rtgpu_math_selfcheck).
+RT_D float sqrt_exact(float s) { return (float)sqrt((double)s); }
+RT_D float sqrt_ref(float s) {
+#if RT_FAST_F64
+  return __builtin_sqrtf(s);
+#else
+  return sqrt_exact(s);
+#endif
+}
 RT_D float dist3(f3 a, f3 b) {
   float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-  return (float)sqrt((double)(dx * dx + dy * dy + dz * dz));
+  return sqrt_ref(dx * dx + dy * dy + dz * dz);
 }
 // vectormath.h:131-136: o + d*r
 RT_D f3 raypoint3(f3 o, f3 r, float d) { return mk3(o.x + d * r.x, o.y + d * r.y, o.z + d * r.z); }

@@ -1216,6 +1216,20 @@ int rtgpu_ticket_log(rtgpu_ctx *c, int which, uint32_t *out, int max_tickets, in
   return RTGPU_OK;
 }
 
+int rtgpu_math_selfcheck(rtgpu_ctx *c, uint64_t mismatches[2]) {
+  if (!c || !mismatches) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  // the frame totals buffer is free between frames: two of its words serve as the counters
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2, c->stream));
+  KLAUNCH(c, k_math_selfcheck, dim3(c->num_cu * 8), dim3(256), c->stream, c->d_totals);
+  unsigned long long bad[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(bad, c->d_totals, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  mismatches[0] = bad[0]; mismatches[1] = bad[1];
+  return RTGPU_OK;
+}
+
 int rtgpu_timings_get(rtgpu_ctx *c, rtgpu_timings *out) {
   if (!c || !out) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));

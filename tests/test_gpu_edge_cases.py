@@ -364,3 +364,18 @@ def test_chunk_size_and_queue_sizing_do_not_change_the_frame(renderer):
         assert np.array_equal(a["ids"], b["ids"])
         assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
         assert np.array_equal(a["minmax"].view(np.uint32), b["minmax"].view(np.uint32))
+
+
+def test_short_forms_of_the_double_precision_idioms_are_exact_for_every_float():
+    """normalize3 and dist3 compute (float)(1.0 / sqrt((double)s)) and (float)sqrt((double)s) (src/vectormath.h:45-48,
+    60-66) by shorter instruction sequences; the library compares both forms on the device for all 2^32 inputs."""
+    import ctypes as C
+    r = rt.Renderer(0)
+    try:
+        L = rt.gpu_lib()
+        L.rtgpu_math_selfcheck.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        bad = (C.c_uint64 * 2)(1, 1)
+        assert L.rtgpu_math_selfcheck(r._h, bad) == 0
+        assert (bad[0], bad[1]) == (0, 0)
+    finally:
+        r.close()
