@@ -444,7 +444,7 @@ RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float spre
 //   batch(k1, k2)      once per surviving batch, with the batch's filter constants
 //   f(record, index, first)  the test of one record, for all lanes (first: pass1 has not seen the record, for the
 //                      statistics); true (wave-uniform) if some lane passed the first slab and the rest of the test ran, and only then
-//   more()             (wave-uniform) is asked: false = stop.
+//   more()             (wave-uniform) is asked after every batch: false = stop.
 //   pass1(record)      the side-effect-free first slab on its own: batches in which most records survive run it for four
 //                      records at a time before f; also for the statistics of diagnostic builds.
 // RECTEST: with the record-level test of the bundle (bundle_slabs_pass) between the ray-by-ray test of the boxes and the
@@ -613,7 +613,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
           if (any != 0) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              if (m[q] != 0 && f(rb + (j + q) * kRecFloats, c0 + (uint32_t)(j + q), false) && !more()) { wait_staged(); ph.template end<5>(); return; }
+              if (m[q] != 0) f(rb + (j + q) * kRecFloats, c0 + (uint32_t)(j + q), false);
             }
           }
         }
@@ -621,8 +621,11 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       }
       for (; todo != 0; todo &= todo - 1) {
         const int j = __ffs(todo) - 1;
-        if (f(rb + j * kRecFloats, c0 + (uint32_t)j, true) && !more()) { wait_staged(); ph.template end<5>(); return; }
+        f(rb + j * kRecFloats, c0 + (uint32_t)j, true);
       }
+      // (asked once per batch, not per record: the records that follow a walk's last blocker test nothing, and the loops
+      // above keep a simple shape)
+      if (!more()) { wait_staged(); ph.template end<5>(); return; }
       __builtin_amdgcn_wave_barrier();
       ph.template end<5, true>();
     }
