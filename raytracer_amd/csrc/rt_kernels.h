@@ -116,6 +116,7 @@ RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, fl
 #endif
 RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
 #if RT_CENTRAL
+  asm volatile("" : "+v"(lane));  // (the key is worked out per visit: as a loop invariant it would be spilled and reloaded)
   const int x2 = 2 * (lane & 7) - 7, y2 = 2 * (lane >> 3) - 7, l2 = 2 * lane - 63;
   const int off = tile ? x2 * x2 + y2 * y2 : (l2 < 0 ? -l2 : l2);
   const float key = in ? (float)(off * 64 + lane) : INFINITY;  // (an integer below 2^13: exact)
@@ -458,6 +459,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
                       bool transparent_counts_anywhere, uint32_t own_sub, uint32_t own_mask, Phases &ph, C &&cull, T &&tally, B &&batch,
                       P &&pass1, F &&f, G &&more) {
   ph.template end<1>();
+  asm volatile("" : "+v"(lane));  // (per-lane addresses below are worked out per visit instead of being kept, spilled, for the whole kernel)
   float *hs = slice;                             // kHdrChunk headers
   float *rs = slice + kHdrChunk * kHdrFloats;    // two buffers of kBatch records
   const TriRec *__restrict__ recs = g.cell_tris;
@@ -478,7 +480,8 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     static_assert(kHdrChunk == 32, "two lanes per batch of a chunk");
     float c0 = INFINITY;
     {
-      const int b = lane & 31;
+      int b = lane & 31;
+      asm volatile("" : "+v"(b));  // (worked out here every time: hoisted out of the loops, the header's LDS address is spilled and reloaded per chunk)
       if (b < nh) {
         const uint32_t left = cnt - (h0 + (uint32_t)b) * kBatch;
         c0 = batch_cos_part(hs + b * kHdrFloats, lane < 32 ? 0 : 4, left < (uint32_t)kBatch ? (int)left : kBatch, bundle);
