@@ -20,6 +20,9 @@
 // the light (the kernels built with ENDS) it pays (ulica 1080p 116.5 against 118.9 ms without).
 #define RT_SHADOW_RAYCULL(RECTEST, ENDS) ((ENDS) || !(RECTEST))
 #endif
+#ifndef RT_OPAQUE_BUNDLE
+#define RT_OPAQUE_BUNDLE 1
+#endif
 #ifndef RT_WAVES
 #define RT_WAVES 6  // waves per SIMD the shadow walk is compiled for (80 VGPRs; with 8 and 64 VGPRs it spills and runs 6 % slower)
 #endif
@@ -455,7 +458,7 @@ RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float spre
 // own_sub, own_mask: for a ticket shared by own_mask + 1 wavefronts, only the header chunks (256 records) whose index
 // & own_mask equals own_sub are looked at (0, 0: all of them).
 template <bool RECTEST, bool ENDS, bool RAYCULL, typename C, typename T, typename B, typename P, typename F, typename G>
-RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle,
+RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle_,
                       bool transparent_counts_anywhere, uint32_t own_sub, uint32_t own_mask, Phases &ph, C &&cull, T &&tally, B &&batch,
                       P &&pass1, F &&f, G &&more) {
   ph.template end<1>();
@@ -467,6 +470,16 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
   const uint32_t nb = (cnt + kBatch - 1) / kBatch;
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
     if (((h0 / kHdrChunk) & own_mask) != own_sub) continue;  // a shared ticket: another wavefront tests this part of the list
+#if RT_OPAQUE_BUNDLE
+    // The bundle's numbers are wave-uniform and live in scalar registers; their products with constants (axis / 511,
+    // 1e-5 onorm, ...) are vector arithmetic, and hoisted out of this loop each holds a vector register for the whole
+    // visit.  Opaque copies keep that arithmetic where it is used.
+    Bundle bundle = bundle_;
+    asm volatile("" : "+s"(bundle.axis.x), "+s"(bundle.axis.y), "+s"(bundle.axis.z), "+s"(bundle.rho), "+s"(bundle.ro), "+s"(bundle.onorm));
+    asm volatile("" : "+s"(bundle.tmax), "+s"(bundle.odr));
+#else
+    const Bundle &bundle = bundle_;
+#endif
     const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
     constexpr int kHdrVecs = kHdrFloats / 4;
     static_assert(kHdrChunk * kHdrVecs <= 192, "up to three 16-byte loads per lane stage a header chunk");
