@@ -136,6 +136,7 @@ RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
 // ray's own last parameter) also have end points o + tend r within re of the leader's, whose range is [0, T]: the
 // bundle of a point light's shadow rays narrows towards the light.  Rays without an end: re = T = infinity.
 struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax, re, T; };
+template <bool ENDS>
 RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, float tmax, float tend, int leader) {
   Bundle b;
   b.axis = lane_bcast3(r, leader);
@@ -156,7 +157,7 @@ RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, floa
   b.onorm = wave_max(on);
   b.tmax = wave_max(tm);
   b.re = INFINITY; b.T = INFINITY;
-  if (tend < INFINITY) {  // (wave-uniform by construction: a walk kernel's rays all end, or none does)
+  if (ENDS) {  // (a walk kernel's rays all end, or none does; decided at compile time, the bundle's numbers stay in scalar registers)
     // end points in float: off the line's own point at tend by at most 3 eps (|o| + tend), covered by 2e-6 (onorm + tend)
     const f3 e = mk3(__builtin_fmaf(tend, r.x, o.x), __builtin_fmaf(tend, r.y, o.y), __builtin_fmaf(tend, r.z, o.z));
     const f3 de = sub3(e, lane_bcast3(e, leader));
@@ -477,6 +478,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     Bundle bundle = bundle_;
     asm volatile("" : "+s"(bundle.axis.x), "+s"(bundle.axis.y), "+s"(bundle.axis.z), "+s"(bundle.rho), "+s"(bundle.ro), "+s"(bundle.onorm));
     asm volatile("" : "+s"(bundle.tmax), "+s"(bundle.odr));
+    if (ENDS) asm volatile("" : "+s"(bundle.re), "+s"(bundle.T));
 #else
     const Bundle &bundle = bundle_;
 #endif
@@ -1392,7 +1394,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell<RECTEST, false, !RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle(proc, o, r, pm, odr, onorm, best, INFINITY, central_lane(proc, lane, prim.on != 0, leader)), false, own_sub, own_mask, ph,
+        stream_cell<RECTEST, false, !RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle<false>(proc, o, r, pm, odr, onorm, best, INFINITY, central_lane(proc, lane, prim.on != 0, leader)), false, own_sub, own_mask, ph,
                     [&](f3 c, float delta, f3 hw, float W) {
                       return wave_mask(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
@@ -1961,7 +1963,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         if (go)
-          stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, make_bundle(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader)), true, own_sub, own_mask, ph,
+          stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, make_bundle<ENDS>(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader)), true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
                         return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },
