@@ -135,7 +135,30 @@ RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
 // and a parameter range that ends before tmax.  Rays that end somewhere (shadow rays, at their lights; tend = the
 // ray's own last parameter) also have end points o + tend r within re of the leader's, whose range is [0, T]: the
 // bundle of a point light's shadow rays narrows towards the light.  Rays without an end: re = T = infinity.
-struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax, re, T; };
+// The shadow rays of ONE point light, as a fan: the ray from a hit point a to the light L has the direction (L - a) / s,
+// s = |L - a|, and the moment a x (L - a) / s = (a x L) / s, so s times each of the filter's quantities is an AFFINE
+// function of a: s det = (L - a).N, s tp = a.(L x ac + Q) - L.Q, s nv = a.(L x ab - P) + L.P (nv = -vp).  Over the box
+// c +- h of the group's hit points such a function stays within sum_k |gradient_k| h_k of its value at c, with the
+// gradients -N, Gt = L x ac + Q, Gv = L x ab - P known exactly: no Lipschitz bound with the longest edge, the fan's
+// narrowing towards the light and a flat patch of hit points are accounted for by themselves (fan_slabs_pass).
+// lo, hi: the box of the hit points; L: the light; smax >= every ray's s.  on = false: no fan (rays of several lights,
+// a planar light's samples, a NaN among the hit points, the nearest-hit walk).
+#ifndef RT_FAN
+#define RT_FAN 1
+#endif
+struct Fan { bool on; f3 lo, hi, L; float smax; };
+struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax, re, T; Fan fan; };
+RT_D Fan no_fan() { Fan f; f.on = false; f.lo = f.hi = f.L = mk3(0.0f, 0.0f, 0.0f); f.smax = 0.0f; return f; }
+RT_D Fan make_fan(bool in, f3 a, f3 L, float smax) {
+  Fan f;
+  f.on = __ballot(in && (a.x != a.x || a.y != a.y || a.z != a.z)) == 0;  // (a NaN would be dropped by the maxima)
+  f.lo = mk3(-wave_max(in ? -a.x : -INFINITY), -wave_max(in ? -a.y : -INFINITY), -wave_max(in ? -a.z : -INFINITY));
+  f.hi = mk3(wave_max(in ? a.x : -INFINITY), wave_max(in ? a.y : -INFINITY), wave_max(in ? a.z : -INFINITY));
+  // (wave-uniform values that vector instructions produced: back into scalar registers)
+  f.L = mk3(lane_bcast(L.x, 0), lane_bcast(L.y, 0), lane_bcast(L.z, 0));
+  f.smax = lane_bcast(smax, 0);
+  return f;
+}
 template <bool ENDS>
 RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, float tmax, float tend, int leader) {
   Bundle b;
@@ -157,6 +180,7 @@ RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, floa
   b.onorm = wave_max(on);
   b.tmax = wave_max(tm);
   b.re = INFINITY; b.T = INFINITY;
+  b.fan = no_fan();
   if (ENDS) {  // (a walk kernel's rays all end, or none does; decided at compile time, the bundle's numbers stay in scalar registers)
     // end points in float: off the line's own point at tend by at most 3 eps (|o| + tend), covered by 2e-6 (onorm + tend)
     const f3 e = mk3(__builtin_fmaf(tend, r.x, o.x), __builtin_fmaf(tend, r.y, o.y), __builtin_fmaf(tend, r.z, o.z));
@@ -442,6 +466,47 @@ RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float spre
   return !((__builtin_fmaxf(__builtin_fabsf(x1), __builtin_fabsf(x2)) > T + E2) | (__builtin_fabsf(x3) > T + (E2 + E2)));
 }
 
+// Can ANY ray of the fan pass the three slabs of this record?  false only if surely none can.  tri_test accepts a ray
+// only if for each slab |X*| <= |det*| (1 + 7 eps) + kc with the exact values on the ray's float inputs (bundle_slabs_pass);
+// times s, and with the ray's float direction within 2 eps of (L - a) / s (which moves X*, det* by less than kc / 50):
+// |X(a)| <= 1.00001 |det(a)| + 1.1 kc s for the affine X, det above.  With |X(a)| >= |X(c)| - spread_X, |det(a)| <=
+// |det(c)| + spread_det, s <= smax, kc <= kc_max, no ray of the fan passes a slab with
+//     |X(c)| - spread_X > 1.00001 (|det(c)| + spread_det) + 3 kc_max smax.
+// Rounding: rc = L - c, mc = c x rc and the dot products in binary32 are off by less than 0.1 kc_max smax per quantity
+// (|c| <= onorm_max; kc = 144 eps L (|o| + A) + 56 eps L^2 with L the longest edge = |ac|), the X(c) by less than 0.5:
+// inside the 3.  The gradients L x ac + Q, L x ab - P cancel where light and triangle lie far from the origin of the
+// coordinates: each is off by at most 4 eps |ac| (|L| + A) <= 0.028 (k1 |L| + k2), times the box: e below covers twice
+// that.  A NaN compares false: passes.
+RT_D bool fan_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float k1max, float k2max, const Fan &f) {
+  const f3 c = mk3(0.5f * (f.lo.x + f.hi.x), 0.5f * (f.lo.y + f.hi.y), 0.5f * (f.lo.z + f.hi.z));
+  // half extents that surely reach both ends from the rounded centre
+  const f3 h = mk3(__builtin_fmaf(__builtin_fmaxf(f.hi.x - c.x, c.x - f.lo.x), 1.000001f, 1e-30f),
+                   __builtin_fmaf(__builtin_fmaxf(f.hi.y - c.y, c.y - f.lo.y), 1.000001f, 1e-30f),
+                   __builtin_fmaf(__builtin_fmaxf(f.hi.z - c.z, c.z - f.lo.z), 1.000001f, 1e-30f));
+  const f3 rc = sub3(f.L, c);
+  const f3 mc = mk3(__builtin_fmaf(c.y, rc.z, -(c.z * rc.y)), __builtin_fmaf(c.z, rc.x, -(c.x * rc.z)), __builtin_fmaf(c.x, rc.y, -(c.y * rc.x)));
+  const float det = __builtin_fmaf(rc.x, A.n.x, __builtin_fmaf(rc.y, A.n.y, rc.z * A.n.z));
+  const float rq = __builtin_fmaf(rc.x, A.q.x, __builtin_fmaf(rc.y, A.q.y, rc.z * A.q.z));
+  const float tp = __builtin_fmaf(mc.x, A.ac.x, __builtin_fmaf(mc.y, A.ac.y, __builtin_fmaf(mc.z, A.ac.z, -rq)));
+  const float rp = __builtin_fmaf(rc.x, P.x, __builtin_fmaf(rc.y, P.y, rc.z * P.z));
+  const float nv = __builtin_fmaf(mc.x, ab.x, __builtin_fmaf(mc.y, ab.y, __builtin_fmaf(mc.z, ab.z, rp)));
+  const float x1 = __builtin_fmaf(2.0f, tp, -det), x2 = __builtin_fmaf(-2.0f, nv, -det), x3 = __builtin_fmaf(2.0f, tp - nv, -det);
+  // gradients with respect to the hit point
+  const f3 gt = mk3(__builtin_fmaf(f.L.y, A.ac.z, __builtin_fmaf(-f.L.z, A.ac.y, A.q.x)), __builtin_fmaf(f.L.z, A.ac.x, __builtin_fmaf(-f.L.x, A.ac.z, A.q.y)),
+                    __builtin_fmaf(f.L.x, A.ac.y, __builtin_fmaf(-f.L.y, A.ac.x, A.q.z)));
+  const f3 gv = mk3(__builtin_fmaf(f.L.y, ab.z, __builtin_fmaf(-f.L.z, ab.y, -P.x)), __builtin_fmaf(f.L.z, ab.x, __builtin_fmaf(-f.L.x, ab.z, -P.y)),
+                    __builtin_fmaf(f.L.x, ab.y, __builtin_fmaf(-f.L.y, ab.x, -P.z)));
+  const f3 g1 = mk3(__builtin_fmaf(2.0f, gt.x, A.n.x), __builtin_fmaf(2.0f, gt.y, A.n.y), __builtin_fmaf(2.0f, gt.z, A.n.z));
+  const f3 g2 = mk3(__builtin_fmaf(-2.0f, gv.x, A.n.x), __builtin_fmaf(-2.0f, gv.y, A.n.y), __builtin_fmaf(-2.0f, gv.z, A.n.z));
+  const f3 g3 = mk3(__builtin_fmaf(-2.0f, gv.x, g1.x), __builtin_fmaf(-2.0f, gv.y, g1.y), __builtin_fmaf(-2.0f, gv.z, g1.z));
+  auto over_box = [&](f3 v) { return __builtin_fmaf(__builtin_fabsf(v.x), h.x, __builtin_fmaf(__builtin_fabsf(v.y), h.y, __builtin_fabsf(v.z) * h.z)); };
+  const float lnorm = __builtin_fabsf(f.L.x) + __builtin_fabsf(f.L.y) + __builtin_fabsf(f.L.z);
+  const float e = 0.06f * __builtin_fmaf(k1max, lnorm, k2max) * (h.x + h.y + h.z);
+  const float T = __builtin_fmaf(__builtin_fabsf(det) + over_box(A.n), 1.00001f, 3.0f * kc_max * f.smax);
+  const float s1 = __builtin_fmaf(over_box(g1), 1.001f, e + e), s2 = __builtin_fmaf(over_box(g2), 1.001f, e + e), s3 = __builtin_fmaf(over_box(g3), 1.001f, 4.0f * e);
+  return !((__builtin_fabsf(x1) - s1 > T) | (__builtin_fabsf(x2) - s2 > T) | (__builtin_fabsf(x3) - s3 > T));
+}
+
 // Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
 // batch the bundle's leader ray, widened to contain every ray of the bundle, is tested against the batch's box first (one
 // lane per batch); for the batches that remain cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides
@@ -478,6 +543,12 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     Bundle bundle = bundle_;
     asm volatile("" : "+s"(bundle.axis.x), "+s"(bundle.axis.y), "+s"(bundle.axis.z), "+s"(bundle.rho), "+s"(bundle.ro), "+s"(bundle.onorm));
     asm volatile("" : "+s"(bundle.tmax), "+s"(bundle.odr));
+#if RT_FAN
+    if (RECTEST && !ENDS && bundle.fan.on) {
+      asm volatile("" : "+s"(bundle.fan.lo.x), "+s"(bundle.fan.lo.y), "+s"(bundle.fan.lo.z), "+s"(bundle.fan.hi.x), "+s"(bundle.fan.hi.y), "+s"(bundle.fan.hi.z));
+      asm volatile("" : "+s"(bundle.fan.L.x), "+s"(bundle.fan.L.y), "+s"(bundle.fan.L.z), "+s"(bundle.fan.smax));
+    }
+#endif
     if (ENDS) asm volatile("" : "+s"(bundle.re), "+s"(bundle.T));
 #else
     const Bundle &bundle = bundle_;
@@ -552,7 +623,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
       const uint32_t kept_all = (uint32_t)kept;
       const int nkept = __popc(kept_all);
       int *number = reinterpret_cast<int *>(rs);  // (the record buffers are not in use yet)
-      if (lane < kHdrChunk && ((kept_all >> lane) & 1u)) number[__popc(kept_all & ((1u << lane) - 1u))] = lane;
+      if (lane < kHdrChunk && ((kept_all >> lane) & 1u)) number[__builtin_amdgcn_mbcnt_lo(kept_all, 0u)] = lane;  // (mbcnt: the kept batches below this lane)
       __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
       for (int p0 = 0; p0 < nkept; p0 += 8) {
@@ -568,7 +639,15 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
             const RecB Rb = rec_b(R);
             const float *H = hs + b * kHdrFloats;
             const float kc_max = __builtin_fmaf(H[8], bundle.onorm, __builtin_fabsf(H[9])) + g.slack;
+#if RT_FAN == 2
+            if (!ENDS && bundle.fan.on) pass = fan_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[8], __builtin_fabsf(H[9]), bundle.fan);
+            else pass = bundle_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[10], bundle);
+#else
             pass = bundle_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[10], bundle);
+#if RT_FAN
+            if (!ENDS && bundle.fan.on && pass) pass = fan_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[8], __builtin_fabsf(H[9]), bundle.fan);
+#endif
+#endif
           }
         }
         const unsigned long long m = __ballot(pass);
@@ -1962,8 +2041,21 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         // lanes outside the cell, and blocked ones, test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
+        Bundle bundle = make_bundle<ENDS>(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader));
+#if RT_FAN
+        if (RECTEST && !ENDS && go && order == nullptr) {
+          // the group's rays as the fan of one point light, if they all look at the same one (tickets that are a tile's hit
+          // points, in the kernels built without ENDS, i.e. for scenes without secondary rays: with the fan compiled into ulica's
+          // kernel its shadow walks took 119 instead of 107 ms, whichever tickets used it)
+          const int slot_u = __builtin_amdgcn_readlane(slot, leader);
+          if (slot_u < sp.nl && __ballot(in_group && slot != slot_u) == 0) {
+            const LightD lu = sp.lights[slot_u];
+            bundle.fan = make_fan(in_group, a, ld3(lu.p), bundle.tmax * 1.00001f);
+          }
+        }
+#endif
         if (go)
-          stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, make_bundle<ENDS>(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader)), true, own_sub, own_mask, ph,
+          stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, bundle, true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
                         return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },
