@@ -462,3 +462,78 @@ def test_bundles_of_rays_that_end_at_one_point(scale, offset):
     # and the narrowing model culls more than the widening one
     may_wide, _, _, _ = bundle_box_may_hit(H, inv_cos, axis, ml, odl, onb, np.maximum(dmax, Tl), ro, rho)
     assert may.sum() <= may_wide.sum()
+
+
+def fan_slabs_pass(T, kc_max, lo, hi, light, smax):
+    """fan_slabs_pass of rt_kernels.h, operation by operation in float32: may any shadow ray of the point light `light`
+    that starts in the box lo..hi pass the record's three slabs?"""
+    N, ac, Q, ab, P = T["N"], T["ac"], T["Q"], T["ab"], T["P"]
+    k = lambda x: np.full(len(N), F(x))
+    with np.errstate(all="ignore"):
+        c = (F(0.5) * (lo + hi)).astype(F)
+        h = fma(np.maximum(hi - c, c - lo), np.full_like(c, F(1.000001)), np.full_like(c, F(1e-30)))
+        rc = (light - c).astype(F)
+        mc = np.stack([fma(c[:, 1], rc[:, 2], -(c[:, 2] * rc[:, 1])), fma(c[:, 2], rc[:, 0], -(c[:, 0] * rc[:, 2])),
+                       fma(c[:, 0], rc[:, 1], -(c[:, 1] * rc[:, 0]))], 1)
+        det = fma(rc[:, 0], N[:, 0], fma(rc[:, 1], N[:, 1], rc[:, 2] * N[:, 2]))
+        rq = fma(rc[:, 0], Q[:, 0], fma(rc[:, 1], Q[:, 1], rc[:, 2] * Q[:, 2]))
+        tp = fma(mc[:, 0], ac[:, 0], fma(mc[:, 1], ac[:, 1], fma(mc[:, 2], ac[:, 2], -rq)))
+        rp = fma(rc[:, 0], P[:, 0], fma(rc[:, 1], P[:, 1], rc[:, 2] * P[:, 2]))
+        nv = fma(mc[:, 0], ab[:, 0], fma(mc[:, 1], ab[:, 1], fma(mc[:, 2], ab[:, 2], rp)))
+        x1, x2, x3 = fma(k(2), tp, -det), fma(k(-2), nv, -det), fma(k(2), tp - nv, -det)
+        Lx, Ly, Lz = light[:, 0], light[:, 1], light[:, 2]
+        gt = np.stack([fma(Ly, ac[:, 2], fma(-Lz, ac[:, 1], Q[:, 0])), fma(Lz, ac[:, 0], fma(-Lx, ac[:, 2], Q[:, 1])),
+                       fma(Lx, ac[:, 1], fma(-Ly, ac[:, 0], Q[:, 2]))], 1)
+        gv = np.stack([fma(Ly, ab[:, 2], fma(-Lz, ab[:, 1], -P[:, 0])), fma(Lz, ab[:, 0], fma(-Lx, ab[:, 2], -P[:, 1])),
+                       fma(Lx, ab[:, 1], fma(-Ly, ab[:, 0], -P[:, 2]))], 1)
+        two = np.full_like(gt, F(2))
+        g1 = fma(two, gt, N)
+        g2 = fma(-two, gv, N)
+        g3 = fma(-two, gv, g1)
+        over = lambda v: fma(np.abs(v[:, 0]), h[:, 0], fma(np.abs(v[:, 1]), h[:, 1], np.abs(v[:, 2]) * h[:, 2]))
+        lnorm = np.abs(Lx) + np.abs(Ly) + np.abs(Lz)
+        e = F(0.06) * fma(T["k1"], lnorm, np.abs(T["k2"])) * (h[:, 0] + h[:, 1] + h[:, 2])
+        Tt = fma(np.abs(det) + over(N), k(1.00001), F(3.0) * kc_max * smax)
+        s1, s2, s3 = fma(over(g1), k(1.001), e + e), fma(over(g2), k(1.001), e + e), fma(over(g3), k(1.001), F(4.0) * e)
+        return ~((np.abs(x1) - s1 > Tt) | (np.abs(x2) - s2 > Tt) | (np.abs(x3) - s3 > Tt))
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.05, 20.0), (10.0, -200.0), (1.0, 3000.0)])
+@pytest.mark.parametrize("box", ["point", "patch", "flat", "wide"])
+def test_fan_of_a_point_lights_shadow_rays(scale, offset, box):
+    """The record-level test for the shadow rays of one point light (fan_slabs_pass): whatever box of hit points holds
+    the ray's origin (the origin alone, a small patch around it, a patch that is flat in one axis, a box as large as the
+    scene), a triangle the exact test accepts for the ray is never dropped.  Rays aimed at edges and vertices, lights
+    before, on and beyond the triangle, coordinates far from the origin (where the gradients cancel)."""
+    rng = np.random.default_rng(int(scale * 1000) + int(offset) + len(box))
+    n = 300000
+    a, ab, ac, o, r0 = make_cases(rng, n, scale, offset, aim_edges)
+    d0 = np.linalg.norm((a - o).astype(np.float64), axis=1) + 1e-30
+    light = (o.astype(np.float64) + r0.astype(np.float64) * (d0 * 10.0 ** rng.uniform(-0.5, 0.5, n))[:, None]).astype(F)
+    rr = (light - o).astype(F)
+    s2 = rr[:, 0] * rr[:, 0] + rr[:, 1] * rr[:, 1] + rr[:, 2] * rr[:, 2]
+    r = rr * (1.0 / np.sqrt(s2.astype(np.float64))).astype(F)[:, None]
+    dmax = np.sqrt(s2.astype(np.float64)).astype(F)
+    acc, acc_uv, d, u, v, det = exact_test(a, ab, ac, o, r)
+    assert acc.mean() > 0.05
+    size = {"point": 0.0, "patch": 10.0 ** rng.uniform(-3, -1, (n, 1)), "flat": 10.0 ** rng.uniform(-3, -1, (n, 1)), "wide": 3.0}[box]
+    other = (o + (rng.standard_normal((n, 3)) * scale * size).astype(F)).astype(F)
+    if box == "flat":
+        ax = rng.integers(0, 3, n)
+        other[np.arange(n), ax] = o[np.arange(n), ax]
+    lo, hi = np.minimum(o, other), np.maximum(o, other)
+    T = preprocess(a, ab, ac)
+    _, on1, _ = ray_side(o, r)
+    _, on2, _ = ray_side(other, r)
+    kc_max = fma(T["k1"], np.maximum(on1, on2), np.abs(T["k2"]))
+    ro = (light - other).astype(np.float64)
+    smax = (np.maximum(dmax, np.sqrt((ro * ro).sum(1)).astype(F)) * F(1.00001)).astype(F)
+    keep = fan_slabs_pass(T, kc_max, lo, hi, light, smax)
+    assert keep[acc].all(), "the fan's record-level test dropped a triangle a ray of the fan hits"
+    if box in ("point", "patch") and offset == 0.0:
+        # and it does drop records: the same fans against triangles somewhere else
+        T2 = preprocess(np.roll(a, 1, 0), np.roll(ab, 1, 0), np.roll(ac, 1, 0))
+        acc2 = exact_test(np.roll(a, 1, 0), np.roll(ab, 1, 0), np.roll(ac, 1, 0), o, r)[0]
+        keep2 = fan_slabs_pass(T2, fma(T2["k1"], np.maximum(on1, on2), np.abs(T2["k2"])), lo, hi, light, smax)
+        assert keep2[acc2].all()
+        assert (~keep2).mean() > 0.3
