@@ -141,22 +141,32 @@ RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
 // c +- h of the group's hit points such a function stays within sum_k |gradient_k| h_k of its value at c, with the
 // gradients -N, Gt = L x ac + Q, Gv = L x ab - P known exactly: no Lipschitz bound with the longest edge, the fan's
 // narrowing towards the light and a flat patch of hit points are accounted for by themselves (fan_slabs_pass).
-// lo, hi: the box of the hit points; L: the light; smax >= every ray's s.  on = false: no fan (rays of several lights,
+// c +- h: the box of the hit points; L: the light; smax >= every ray's s.  on = false: no fan (rays of several lights,
 // a planar light's samples, a NaN among the hit points, the nearest-hit walk).
 #ifndef RT_FAN
 #define RT_FAN 1
 #endif
-struct Fan { bool on; f3 lo, hi, L; float smax; };
+struct Fan { bool on; f3 c, h, rc, mc, L; float smax, hsum, lnorm; };  // c +- h: the box; rc = L - c, mc = c x rc; hsum = h.x + h.y + h.z, lnorm >= |L|
 struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax, re, T; Fan fan; };
-RT_D Fan no_fan() { Fan f; f.on = false; f.lo = f.hi = f.L = mk3(0.0f, 0.0f, 0.0f); f.smax = 0.0f; return f; }
+RT_D Fan no_fan() { Fan f; f.on = false; f.c = f.h = f.rc = f.mc = f.L = mk3(0.0f, 0.0f, 0.0f); f.smax = f.hsum = f.lnorm = 0.0f; return f; }
 RT_D Fan make_fan(bool in, f3 a, f3 L, float smax) {
   Fan f;
   f.on = __ballot(in && (a.x != a.x || a.y != a.y || a.z != a.z)) == 0;  // (a NaN would be dropped by the maxima)
-  f.lo = mk3(-wave_max(in ? -a.x : -INFINITY), -wave_max(in ? -a.y : -INFINITY), -wave_max(in ? -a.z : -INFINITY));
-  f.hi = mk3(wave_max(in ? a.x : -INFINITY), wave_max(in ? a.y : -INFINITY), wave_max(in ? a.z : -INFINITY));
-  // (wave-uniform values that vector instructions produced: back into scalar registers)
-  f.L = mk3(lane_bcast(L.x, 0), lane_bcast(L.y, 0), lane_bcast(L.z, 0));
+  const f3 lo = mk3(-wave_max(in ? -a.x : -INFINITY), -wave_max(in ? -a.y : -INFINITY), -wave_max(in ? -a.z : -INFINITY));
+  const f3 hi = mk3(wave_max(in ? a.x : -INFINITY), wave_max(in ? a.y : -INFINITY), wave_max(in ? a.z : -INFINITY));
+  const f3 c = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+  // half extents that surely reach both ends from the rounded centre
+  const f3 h = mk3(__builtin_fmaf(__builtin_fmaxf(hi.x - c.x, c.x - lo.x), 1.000001f, 1e-30f),
+                   __builtin_fmaf(__builtin_fmaxf(hi.y - c.y, c.y - lo.y), 1.000001f, 1e-30f),
+                   __builtin_fmaf(__builtin_fmaxf(hi.z - c.z, c.z - lo.z), 1.000001f, 1e-30f));
+  const f3 rc = sub3(L, c);
+  const f3 mc = mk3(__builtin_fmaf(c.y, rc.z, -(c.z * rc.y)), __builtin_fmaf(c.z, rc.x, -(c.x * rc.z)), __builtin_fmaf(c.x, rc.y, -(c.y * rc.x)));
+  // (wave-uniform values that vector instructions produced: once per visit, back into scalar registers, so that the
+  // record test reads them as scalar operands instead of holding fifteen vector registers)
+  f.c = lane_bcast3(c, 0); f.h = lane_bcast3(h, 0); f.rc = lane_bcast3(rc, 0); f.mc = lane_bcast3(mc, 0); f.L = lane_bcast3(L, 0);
   f.smax = lane_bcast(smax, 0);
+  f.hsum = lane_bcast(h.x + h.y + h.z, 0);
+  f.lnorm = lane_bcast(__builtin_fabsf(L.x) + __builtin_fabsf(L.y) + __builtin_fabsf(L.z), 0);
   return f;
 }
 template <bool ENDS>
@@ -478,13 +488,7 @@ RT_D bool bundle_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float spre
 // coordinates: each is off by at most 4 eps |ac| (|L| + A) <= 0.028 (k1 |L| + k2), times the box: e below covers twice
 // that.  A NaN compares false: passes.
 RT_D bool fan_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float k1max, float k2max, const Fan &f) {
-  const f3 c = mk3(0.5f * (f.lo.x + f.hi.x), 0.5f * (f.lo.y + f.hi.y), 0.5f * (f.lo.z + f.hi.z));
-  // half extents that surely reach both ends from the rounded centre
-  const f3 h = mk3(__builtin_fmaf(__builtin_fmaxf(f.hi.x - c.x, c.x - f.lo.x), 1.000001f, 1e-30f),
-                   __builtin_fmaf(__builtin_fmaxf(f.hi.y - c.y, c.y - f.lo.y), 1.000001f, 1e-30f),
-                   __builtin_fmaf(__builtin_fmaxf(f.hi.z - c.z, c.z - f.lo.z), 1.000001f, 1e-30f));
-  const f3 rc = sub3(f.L, c);
-  const f3 mc = mk3(__builtin_fmaf(c.y, rc.z, -(c.z * rc.y)), __builtin_fmaf(c.z, rc.x, -(c.x * rc.z)), __builtin_fmaf(c.x, rc.y, -(c.y * rc.x)));
+  const f3 h = f.h, rc = f.rc, mc = f.mc;
   const float det = __builtin_fmaf(rc.x, A.n.x, __builtin_fmaf(rc.y, A.n.y, rc.z * A.n.z));
   const float rq = __builtin_fmaf(rc.x, A.q.x, __builtin_fmaf(rc.y, A.q.y, rc.z * A.q.z));
   const float tp = __builtin_fmaf(mc.x, A.ac.x, __builtin_fmaf(mc.y, A.ac.y, __builtin_fmaf(mc.z, A.ac.z, -rq)));
@@ -500,8 +504,7 @@ RT_D bool fan_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float k1max, 
   const f3 g2 = mk3(__builtin_fmaf(-2.0f, gv.x, A.n.x), __builtin_fmaf(-2.0f, gv.y, A.n.y), __builtin_fmaf(-2.0f, gv.z, A.n.z));
   const f3 g3 = mk3(__builtin_fmaf(-2.0f, gv.x, g1.x), __builtin_fmaf(-2.0f, gv.y, g1.y), __builtin_fmaf(-2.0f, gv.z, g1.z));
   auto over_box = [&](f3 v) { return __builtin_fmaf(__builtin_fabsf(v.x), h.x, __builtin_fmaf(__builtin_fabsf(v.y), h.y, __builtin_fabsf(v.z) * h.z)); };
-  const float lnorm = __builtin_fabsf(f.L.x) + __builtin_fabsf(f.L.y) + __builtin_fabsf(f.L.z);
-  const float e = 0.06f * __builtin_fmaf(k1max, lnorm, k2max) * (h.x + h.y + h.z);
+  const float e = 0.06f * __builtin_fmaf(k1max, f.lnorm, k2max) * f.hsum;
   const float T = __builtin_fmaf(__builtin_fabsf(det) + over_box(A.n), 1.00001f, 3.0f * kc_max * f.smax);
   const float s1 = __builtin_fmaf(over_box(g1), 1.001f, e + e), s2 = __builtin_fmaf(over_box(g2), 1.001f, e + e), s3 = __builtin_fmaf(over_box(g3), 1.001f, 4.0f * e);
   return !((__builtin_fabsf(x1) - s1 > T) | (__builtin_fabsf(x2) - s2 > T) | (__builtin_fabsf(x3) - s3 > T));
@@ -545,8 +548,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     asm volatile("" : "+s"(bundle.tmax), "+s"(bundle.odr));
 #if RT_FAN
     if (RECTEST && !ENDS && bundle.fan.on) {
-      asm volatile("" : "+s"(bundle.fan.lo.x), "+s"(bundle.fan.lo.y), "+s"(bundle.fan.lo.z), "+s"(bundle.fan.hi.x), "+s"(bundle.fan.hi.y), "+s"(bundle.fan.hi.z));
-      asm volatile("" : "+s"(bundle.fan.L.x), "+s"(bundle.fan.L.y), "+s"(bundle.fan.L.z), "+s"(bundle.fan.smax));
+      asm volatile("" : "+s"(bundle.fan.smax), "+s"(bundle.fan.hsum), "+s"(bundle.fan.lnorm));
     }
 #endif
     if (ENDS) asm volatile("" : "+s"(bundle.re), "+s"(bundle.T));
