@@ -1945,6 +1945,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     Walk w;
     w.cell = 0;
     uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
+    f3 light = mk3(0.0f, 0.0f, 0.0f);  // where this lane's ray ends
     if (item < total) {
       // slot = item / n: one division per wavefront; its 64 items span at most two slots unless the queue is tiny
       const uint32_t slot0 = base / (uint32_t)n, rest = base - slot0 * (uint32_t)n + (uint32_t)lane;
@@ -1966,6 +1967,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         a = ld3(nd.p);
         f3 b, lcol; float lflux;
         slot_light(sp, slot, rand_rank ? rand_rank[node_base + nidx] : 0, b, lflux, lcol);
+        light = b;
         r = ray3(a, b);
         const float kt_cur = sp.surf[sp.tri_sid[current]].kt;
         bool lit_walk = true;
@@ -1991,6 +1993,22 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
       if (COUNT) nT += mycnt;
     }
+    // The ticket's walks as the fan of one point light, if they all end at the same one (tickets that are a tile's hit
+    // points, in the kernels built without ENDS, i.e. for scenes without secondary rays: with the fan compiled into ulica's
+    // kernel its shadow walks took 114 instead of 107 ms, whichever tickets used it).  Built once per ticket, from all its
+    // walks: the groups of its cell visits are nearly the whole ticket.
+    Fan ticket_fan = no_fan();
+#if RT_FAN
+    if (RECTEST && !ENDS && order == nullptr) {
+      const unsigned long long walking = __ballot(alive);
+      if (walking != 0) {
+        const int first = __ffsll(walking) - 1;
+        const int slot_t = __builtin_amdgcn_readlane(slot, first);
+        if (slot_t < sp.nl && __ballot(alive && slot != slot_t) == 0)
+          ticket_fan = make_fan(alive, a, lane_bcast3(light, first), wave_max(alive ? dmax : 0.0f) * 1.00001f);
+      }
+    }
+#endif
     ph.end<0>();
     for (;;) {
       const unsigned long long m = __ballot(alive);
@@ -2044,18 +2062,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
         Bundle bundle = make_bundle<ENDS>(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader));
-#if RT_FAN
-        if (RECTEST && !ENDS && go && order == nullptr) {
-          // the group's rays as the fan of one point light, if they all look at the same one (tickets that are a tile's hit
-          // points, in the kernels built without ENDS, i.e. for scenes without secondary rays: with the fan compiled into ulica's
-          // kernel its shadow walks took 119 instead of 107 ms, whichever tickets used it)
-          const int slot_u = __builtin_amdgcn_readlane(slot, leader);
-          if (slot_u < sp.nl && __ballot(in_group && slot != slot_u) == 0) {
-            const LightD lu = sp.lights[slot_u];
-            bundle.fan = make_fan(in_group, a, ld3(lu.p), bundle.tmax * 1.00001f);
-          }
-        }
-#endif
+        bundle.fan = ticket_fan;
         if (go)
           stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, bundle, true, own_sub, own_mask, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
