@@ -23,6 +23,12 @@
 #ifndef RT_OPAQUE_BUNDLE
 #define RT_OPAQUE_BUNDLE 1
 #endif
+#ifndef RT_WAVES_ACC
+#define RT_WAVES_ACC 4  // k_accumulate: 128 instead of 131 registers buy a fourth wave per SIMD (0.27 -> 0.23 ms); five spill (0.51 ms)
+#endif
+#ifndef RT_WAVES_HIT
+#define RT_WAVES_HIT 4  // k_hit: five waves per SIMD spill (0.14 -> 0.28 ms)
+#endif
 #ifndef RT_WAVES
 #define RT_WAVES 6  // waves per SIMD the shadow walk is compiled for (80 VGPRs; with 8 and 64 VGPRs it spills and runs 6 % slower)
 #endif
@@ -1732,7 +1738,7 @@ __global__ void __launch_bounds__(256) k_order_place(GridP g, const SOrigin *__r
 // secondary rays.  Normal flip, surface colour, procedural texture + bump (fused here), reflected and
 // refracted rays.  Children are appended to the next level's queue with one atomic per wavefront
 // (ballot + prefix count), so a child's slot is its parent's link.
-__global__ void __launch_bounds__(256) k_hit(GridP g, ShadeP sp, const Ray *__restrict__ rays, const Hit *__restrict__ hits,
+__global__ void __launch_bounds__(256, RT_WAVES_HIT) k_hit(GridP g, ShadeP sp, const Ray *__restrict__ rays, const Hit *__restrict__ hits,
                                              Node *__restrict__ nodes, SOrigin *__restrict__ sorg, const float *__restrict__ geom,
                                              Ray *__restrict__ next_rays, Ctl *__restrict__ ctl, int level,
                                              int node_base, int next_base, int next_cap, bool spawn, PrimaryP prim) {
@@ -2230,7 +2236,7 @@ RT_D f3 light_term(const SurfaceD &sf, f3 norm, f3 r, f3 rnew, f3 onew, f3 lpos,
 // ambient, + kr * reflected child, + kt * refracted child, + point lights in order, + planar lights
 // (16 samples each, accumulated exactly as written, quirks included).  Levels run deepest first so a
 // node finds its children's colours ready.  Level 0 also writes the tile-major framebuffer.
-__global__ void __launch_bounds__(256) k_accumulate(ShadeP sp, const Ray *__restrict__ rays, const Node *__restrict__ nodes,
+__global__ void __launch_bounds__(256, RT_WAVES_ACC) k_accumulate(ShadeP sp, const Ray *__restrict__ rays, const Node *__restrict__ nodes,
                                                     const float *__restrict__ ts_in, long long ts_stride, const int32_t *__restrict__ rand_rank,
                                                     float *__restrict__ colors, Ctl *__restrict__ ctl, int level,
                                                     int node_base, float *__restrict__ fb_rgb, int32_t *__restrict__ fb_ids,
