@@ -55,6 +55,22 @@ static int gpu_failed(rtgpu_ctx *ctx, int rc) {
   return rc;
 }
 
+
+/* The frame's big host buffers (colours, ids, the pixel map) are kept from call to call: fresh pages for 330 MB per 4K
+ * frame cost more than the GPU frame itself.  grab() hands out the cached block if it is large enough (taking it out of
+ * the cache), keep() puts a block back in place of a smaller or absent one. */
+struct held { void *p; size_t bytes; };
+static struct held held_rgb, held_ids, held_map;
+static void *grab(struct held *h, size_t bytes, int zero) {
+  void *p;
+  if (h->p && h->bytes >= bytes) { p = h->p; h->p = NULL; h->bytes = 0; if (zero) memset(p, 0, bytes); return p; }
+  return zero ? calloc(1, bytes ? bytes : 1) : malloc(bytes ? bytes : 1);
+}
+static void keep(struct held *h, void *p, size_t bytes) {
+  if (!p) return;
+  if (!h->p || h->bytes < bytes) { free(h->p); h->p = p; h->bytes = bytes; } else free(p);
+}
+
 RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera) {
   const size_t np = (size_t)camera->sw * (size_t)camera->sh;
   const int32_t nt = scene->nt, ns = scene->ns, nl = scene->nl, npl = scene->npl;
@@ -72,7 +88,7 @@ RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera
   int k, ok = 0, saved;
   size_t p;
 
-  if (!res || !(res->map = calloc(np ? np : 1, sizeof *res->map))) { errno = E_MEMORY; goto out; }
+  if (!res || !(res->map = grab(&held_map, (np ? np : 1) * sizeof *res->map, np == 0))) { errno = E_MEMORY; goto out; }
   res->width = camera->sw;
   res->height = camera->sh;
   res->gamma = scene->cfg.gamma > 0.0f ? scene->cfg.gamma : 2.5f; /* src/raytrace.c:333-337 */
@@ -86,8 +102,8 @@ RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera
   surf = calloc((size_t)ns + 1, sizeof *surf);
   lgt = calloc((size_t)nl + 1, sizeof *lgt);
   pl = calloc((size_t)npl + 1, sizeof *pl);
-  rgb = malloc(sizeof(float) * 3 * (np ? np : 1));
-  ids = malloc(sizeof(int32_t) * (np ? np : 1));
+  rgb = grab(&held_rgb, sizeof(float) * 3 * (np ? np : 1), 0);
+  ids = grab(&held_ids, sizeof(int32_t) * (np ? np : 1), 0);
   if (!verts || !sid || !surf || !lgt || !pl || !rgb || !ids) { errno = E_MEMORY; goto out; }
   memset(&d, 0, sizeof d);
   for (i = 0; i < nt; i++) {
@@ -138,17 +154,22 @@ RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera
   res->min.c[3] = FLT_MAX; res->max.c[3] = FLT_MIN; /* src/raytrace.c:317-320: the alpha lane is never updated */
   for (p = 0; p < np; p++) {
     res->map[p].c.c[0] = rgb[3 * p]; res->map[p].c.c[1] = rgb[3 * p + 1]; res->map[p].c.c[2] = rgb[3 * p + 2];
+    res->map[p].c.c[3] = 0.0f; /* (the reference's map comes from calloc) */
     res->map[p].t = ids[p] >= 0 ? &scene->t[ids[p]] : NULL;
   }
   ok = 1;
 out:
-  free(verts); free(sid); free(surf); free(lgt); free(pl); free(rgb); free(ids);
+  free(verts); free(sid); free(surf); free(lgt); free(pl);
+  keep(&held_rgb, rgb, sizeof(float) * 3 * (np ? np : 1)); keep(&held_ids, ids, sizeof(int32_t) * (np ? np : 1));
   if (!ok) rtVisualizedSceneDestroy(&res);
   return res;
 }
 
 void rtVisualizedSceneDestroy(RT_VisualizedScene **self) {
-  if (self && *self) { free((*self)->map); free(*self); *self = NULL; }
+  if (self && *self) {
+    keep(&held_map, (*self)->map, (size_t)((*self)->width > 0 ? (*self)->width : 0) * (size_t)((*self)->height > 0 ? (*self)->height : 0) * sizeof *(*self)->map);
+    free(*self); *self = NULL;
+  }
 }
 
 RT_Bitmap *rtVisualizedSceneToBitmap(RT_VisualizedScene *s, int flags, void *param1) {
@@ -167,12 +188,12 @@ RT_Bitmap *rtVisualizedSceneToBitmap(RT_VisualizedScene *s, int flags, void *par
   }
   saved = errno;
   if (!(ctx = context())) { rtBitmapDestroy(&bmp); return NULL; }
-  rgb = malloc(sizeof(float) * 3 * (np ? np : 1));
+  rgb = grab(&held_rgb, sizeof(float) * 3 * (np ? np : 1), 0);
   if (!rgb) { errno = E_MEMORY; rtBitmapDestroy(&bmp); return NULL; }
   for (p = 0; p < np; p++) for (k = 0; k < 3; k++) rgb[3 * p + k] = s->map[p].c.c[k];
   for (k = 0; k < 3; k++) { mm[k] = s->min.c[k]; mm[3 + k] = s->max.c[k]; }
   if (gpu_failed(ctx, rtgpu_tonemap_host(ctx, rgb, (int64_t)np, mm, gamma, bmp->pixels))) rtBitmapDestroy(&bmp);
   else errno = saved;
-  free(rgb);
+  keep(&held_rgb, rgb, sizeof(float) * 3 * (np ? np : 1));
   return bmp;
 }
