@@ -12,6 +12,10 @@
  * fixes the order of the reference's rand() draws (src/raytrace.c:245-251): rtgpu_render_trace, rtgpu_hit_counts,
  * ncclAllGather, rtgpu_render_shade.
  * With N = 1 the same calls are issued to a communicator of one rank.
+ * With N > 1 two frames are in flight (RTGPU_FRAMES_IN_FLIGHT overrides, 1..2): a device's share of a frame leaves most of
+ * it idle for most of a walk kernel, so frame k runs in slot k mod 2, and every slot has its own contexts, streams,
+ * buffers and its own communicators (collectives of one communicator must execute in the order they were issued on
+ * every device, which two streams do not guarantee).
  *
  * Built as its own library (librtmulti.so) because it is the only part of the host layer that needs RCCL; the command
  * line loads it when --devices is given.
@@ -27,6 +31,7 @@
 #include "rt_host.h"
 
 #define RT_MAX_DEVICES 64
+#define RT_MAX_DEPTH 2
 
 void rtTilePlan(int32_t width, int32_t height, int ndev, int64_t *tiles, int64_t *first_pixel); /* scene.c */
 
@@ -62,20 +67,26 @@ static int gpu_failed(rtgpu_ctx *ctx, int rc, const char *what) {
  * failure).  seconds (optional): wall time per frame of the frames after the first, everything included from
  * rtgpu_frame_begin to the finished image on device 0. */
 RT_Bitmap *rtHostRenderDevices(RT_Scene *scene, RT_Camera *camera, int ndev, int frames, double *seconds) {
-  Rank rk[RT_MAX_DEVICES];
-  ncclComm_t comm[RT_MAX_DEVICES];
-  int devs[RT_MAX_DEVICES], have_comm = 0, r, f, k, avail = 0;
+  static Rank slots[RT_MAX_DEPTH][RT_MAX_DEVICES];
+  static ncclComm_t comms[RT_MAX_DEPTH][RT_MAX_DEVICES];
+  Rank *rk;
+  ncclComm_t *comm;
+  int devs[RT_MAX_DEVICES], have_comm = 0, r, f, k, avail = 0, depth, sl;
   int64_t tiles[RT_MAX_DEVICES], first[RT_MAX_DEVICES + 1], most = 0;
   const int64_t np = (int64_t)camera->sw * camera->sh;
   const float gamma = scene->cfg.gamma > 0.0f ? scene->cfg.gamma : 2.5f; /* src/raytrace.c:333-337 */
   RT_SceneFlat *flat = NULL;
   RT_Bitmap *bmp = NULL;
-  uint32_t *gathered = NULL, *image = NULL;
+  uint32_t *gathered_s[RT_MAX_DEPTH] = {NULL, NULL}, *image_s[RT_MAX_DEPTH] = {NULL, NULL}, *gathered, *image = NULL;
+  const char *env = getenv("RTGPU_FRAMES_IN_FLIGHT");
   rtgpu_camera cam;
   struct timespec t0, t1;
   int ok = 0;
 
-  memset(rk, 0, sizeof rk);
+  memset(slots, 0, sizeof slots);
+  depth = env ? atoi(env) : (ndev > 1 ? 2 : 1);
+  if (depth < 1) depth = 1;
+  if (depth > RT_MAX_DEPTH) depth = RT_MAX_DEPTH;
   if (ndev < 1 || ndev > RT_MAX_DEVICES || frames < 1) { errno = E_INVALID_PARAM_VALUE; return NULL; }
   if (hip_failed(hipGetDeviceCount(&avail), "hipGetDeviceCount") || avail < ndev) {
     fprintf(stderr, "rtHostRenderDevices: %d devices asked for, %d present\n", ndev, avail);
@@ -87,37 +98,41 @@ RT_Bitmap *rtHostRenderDevices(RT_Scene *scene, RT_Camera *camera, int ndev, int
   rtCameraFlatten(camera, &cam);
   rtTilePlan(camera->sw, camera->sh, ndev, tiles, first);
   for (r = 0; r < ndev; r++) { devs[r] = r; if (tiles[r] > most) most = tiles[r]; }
-  NCCLOK(ncclCommInitAll(comm, ndev, devs));
-  have_comm = 1;
-
-  for (r = 0; r < ndev; r++) {
-    Rank *q = &rk[r];
-    q->npix = tiles[r] * 64;
-    HIPOK(hipSetDevice(r));
-    GPUOK(NULL, rtgpu_create(r, &q->ctx));
-    HIPOK(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
-    GPUOK(q->ctx, rtgpu_set_stream(q->ctx, q->stream));
-    GPUOK(q->ctx, rtgpu_scene_upload(q->ctx, &flat->desc));
-    HIPOK(hipMalloc((void **)&q->rgb, sizeof(float) * 3 * (size_t)(q->npix + 1)));
-    HIPOK(hipMalloc((void **)&q->ids, sizeof(int32_t) * (size_t)(q->npix + 1)));
-    HIPOK(hipMalloc((void **)&q->rgba, sizeof(uint32_t) * (size_t)(most * 64 + 1)));
-    HIPOK(hipMalloc((void **)&q->mm, sizeof(float) * 6));
-    if (scene->npl > 0) { /* every rank's counts padded to the largest share */
-      HIPOK(hipMalloc((void **)&q->counts, sizeof(int32_t) * (size_t)(most * 64 + 1)));
-      HIPOK(hipMalloc((void **)&q->all_counts, sizeof(int32_t) * (size_t)(most * 64 * ndev + 1)));
-      HIPOK(hipMemsetAsync(q->counts, 0, sizeof(int32_t) * (size_t)(most * 64 + 1), q->stream));
+  for (sl = 0; sl < depth; sl++) {
+    rk = slots[sl]; comm = comms[sl];
+    NCCLOK(ncclCommInitAll(comm, ndev, devs));
+    have_comm = sl + 1;
+    for (r = 0; r < ndev; r++) {
+      Rank *q = &rk[r];
+      q->npix = tiles[r] * 64;
+      HIPOK(hipSetDevice(r));
+      GPUOK(NULL, rtgpu_create(r, &q->ctx));
+      HIPOK(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+      GPUOK(q->ctx, rtgpu_set_stream(q->ctx, q->stream));
+      GPUOK(q->ctx, rtgpu_scene_upload(q->ctx, &flat->desc));
+      HIPOK(hipMalloc((void **)&q->rgb, sizeof(float) * 3 * (size_t)(q->npix + 1)));
+      HIPOK(hipMalloc((void **)&q->ids, sizeof(int32_t) * (size_t)(q->npix + 1)));
+      HIPOK(hipMalloc((void **)&q->rgba, sizeof(uint32_t) * (size_t)(most * 64 + 1)));
+      HIPOK(hipMalloc((void **)&q->mm, sizeof(float) * 6));
+      if (scene->npl > 0) { /* every rank's counts padded to the largest share */
+        HIPOK(hipMalloc((void **)&q->counts, sizeof(int32_t) * (size_t)(most * 64 + 1)));
+        HIPOK(hipMalloc((void **)&q->all_counts, sizeof(int32_t) * (size_t)(most * 64 * ndev + 1)));
+        HIPOK(hipMemsetAsync(q->counts, 0, sizeof(int32_t) * (size_t)(most * 64 + 1), q->stream));
+      }
     }
+    HIPOK(hipSetDevice(0));
+    HIPOK(hipMalloc((void **)&gathered_s[sl], sizeof(uint32_t) * (size_t)(first[ndev] + 1)));
+    HIPOK(hipMalloc((void **)&image_s[sl], sizeof(uint32_t) * (size_t)(np + 1)));
   }
-  HIPOK(hipSetDevice(0));
-  HIPOK(hipMalloc((void **)&gathered, sizeof(uint32_t) * (size_t)(first[ndev] + 1)));
-  HIPOK(hipMalloc((void **)&image, sizeof(uint32_t) * (size_t)(np + 1)));
 
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (f = 0; f < frames; f++) {
-    if (f == 1) { /* the first frame pays for queues, code objects and the communicator's first use */
-      for (r = 0; r < ndev; r++) { HIPOK(hipSetDevice(r)); HIPOK(hipStreamSynchronize(rk[r].stream)); }
+    if (f == depth) { /* the first frame of every slot pays for queues, code objects and the communicator's first use */
+      for (sl = 0; sl < depth; sl++)
+        for (r = 0; r < ndev; r++) { HIPOK(hipSetDevice(r)); HIPOK(hipStreamSynchronize(slots[sl][r].stream)); }
       clock_gettime(CLOCK_MONOTONIC, &t0);
     }
+    rk = slots[f % depth]; comm = comms[f % depth]; gathered = gathered_s[f % depth]; image = image_s[f % depth];
     for (r = 0; r < ndev; r++) GPUOK(rk[r].ctx, rtgpu_frame_begin(rk[r].ctx, &cam));
     if (scene->npl > 0) {
       int64_t total = 0;
@@ -160,24 +175,26 @@ RT_Bitmap *rtHostRenderDevices(RT_Scene *scene, RT_Camera *camera, int ndev, int
     GPUOK(rk[0].ctx, rtgpu_untile(rk[0].ctx, gathered, ndev, 4, image));
   }
   HIPOK(hipSetDevice(0));
-  HIPOK(hipStreamSynchronize(rk[0].stream));
+  for (sl = 0; sl < depth; sl++) HIPOK(hipStreamSynchronize(slots[sl][0].stream));  /* (image = the last frame's) */
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  if (seconds) *seconds = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / (frames > 1 ? frames - 1 : 1);
+  if (seconds) *seconds = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / (frames > depth ? frames - depth : 1);
   if (!(bmp = rtBitmapCreate(camera->sw, camera->sh, 0))) goto out;
   HIPOK(hipMemcpy(bmp->pixels, image, sizeof(uint32_t) * (size_t)np, hipMemcpyDeviceToHost));
   ok = 1;
 out:
-  for (r = 0; r < ndev; r++) {
-    Rank *q = &rk[r];
-    (void)hipSetDevice(r);
-    if (q->stream) (void)hipStreamSynchronize(q->stream);
-    if (q->ctx) { (void)rtgpu_set_stream(q->ctx, NULL); rtgpu_destroy(q->ctx); }
-    (void)hipFree(q->rgb); (void)hipFree(q->ids); (void)hipFree(q->rgba); (void)hipFree(q->mm); (void)hipFree(q->counts); (void)hipFree(q->all_counts);
-    if (q->stream) (void)hipStreamDestroy(q->stream);
+  for (sl = 0; sl < RT_MAX_DEPTH; sl++) {
+    for (r = 0; r < ndev; r++) {
+      Rank *q = &slots[sl][r];
+      (void)hipSetDevice(r);
+      if (q->stream) (void)hipStreamSynchronize(q->stream);
+      if (q->ctx) { (void)rtgpu_set_stream(q->ctx, NULL); rtgpu_destroy(q->ctx); }
+      (void)hipFree(q->rgb); (void)hipFree(q->ids); (void)hipFree(q->rgba); (void)hipFree(q->mm); (void)hipFree(q->counts); (void)hipFree(q->all_counts);
+      if (q->stream) (void)hipStreamDestroy(q->stream);
+    }
+    (void)hipSetDevice(0);
+    (void)hipFree(gathered_s[sl]); (void)hipFree(image_s[sl]);
+    if (sl < have_comm) for (r = 0; r < ndev; r++) (void)ncclCommDestroy(comms[sl][r]);
   }
-  (void)hipSetDevice(0);
-  (void)hipFree(gathered); (void)hipFree(image);
-  if (have_comm) for (r = 0; r < ndev; r++) (void)ncclCommDestroy(comm[r]);
   rtSceneFlatFree(&flat);
   if (!ok) rtBitmapDestroy(&bmp);
   return bmp;
