@@ -283,16 +283,18 @@ def test_command_line_resolution_override_and_textured_config(tmp_path):
     assert np.array_equal(o["ids"], z["ids"])
 
 
+@pytest.mark.parametrize("depth", [1, 2])
 @pytest.mark.parametrize("name", ["s3", "s2", "temple"])
-def test_command_line_devices_1_issues_the_collectives_and_writes_the_reference_bmp(tmp_path, name):
+def test_command_line_devices_1_issues_the_collectives_and_writes_the_reference_bmp(tmp_path, name, depth):
     """`raytrace --devices 1`: the one-process N-GPU host (host/multigpu.c) with a communicator of one rank: colour range
     all-reduce (MIN and MAX), RGBA8 tile send/receive, and for s2's planar light the all-gather of the hit counts
-    between the two halves of the frame.  The BMP is the reference's."""
+    between the two halves of the frame.  The BMP is the reference's, with one frame in flight and with two (what the
+    host does with N > 1: a second set of contexts, streams, buffers and communicators)."""
     k = KNOWN[name]
     out = str(tmp_path / "o.bmp")
     exe = os.path.join(ROOT, "raytracer_amd", "raytrace")
-    p = subprocess.run([exe, "-s", os.path.join(ROOT, k["prefix"]), "-o", out, "--devices", "1", "--frames", "3"], cwd=str(tmp_path),
-                       capture_output=True, text=True, timeout=300)
+    p = subprocess.run([exe, "-s", os.path.join(ROOT, k["prefix"]), "-o", out, "--devices", "1", "--frames", "5"], cwd=str(tmp_path),
+                       env=dict(os.environ, RTGPU_FRAMES_IN_FLIGHT=str(depth)), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     assert "ray-tracing on 1 device(s) done" in p.stdout
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == k["bmp_sha256"]
