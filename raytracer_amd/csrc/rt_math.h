@@ -325,11 +325,19 @@ RT_D float pl_sdist(f3 N, float an, f3 o, const PlTest &t) {
   return __int_as_float(__float_as_int(dp) ^ (__float_as_int(t.det) & (int)0x80000000));
 }
 // Per-ray side of the filter: m = o x r (double, rounded once), an upper bound of |o|, and o.r.
+// The bound and o.r in binary32: the sum of squares and its root are off by less than 3 eps, far inside the factor
+// 1.0001 (an overflow gives +inf: nothing is culled; squares that underflow, |o| < 1e-18, are covered by the addend);
+// o.r is only used by the box tests, whose delta = 1e-5 (2 |o| + ...) is far above its 3 eps |o|.
 RT_D void pl_ray(f3 o, f3 r, f3 &m, float &onorm, float &odr) {
   const double ox = o.x, oy = o.y, oz = o.z, rx = r.x, ry = r.y, rz = r.z;
   m = mk3((float)(oy * rz - oz * ry), (float)(oz * rx - ox * rz), (float)(ox * ry - oy * rx));
+#if RT_FAST_F64
+  onorm = __builtin_fmaf(__builtin_sqrtf(__builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, o.z * o.z))), 1.0001f, 1e-18f);
+  odr = __builtin_fmaf(o.x, r.x, __builtin_fmaf(o.y, r.y, o.z * r.z));
+#else
   onorm = (float)sqrt(ox * ox + oy * oy + oz * oz) * 1.0001f;
   odr = (float)(ox * rx + oy * ry + oz * rz);
+#endif
 }
 
 // float -> uint32_t as the reference binary converts the tone-mapped channel (64-bit cvttss2si, low

@@ -74,10 +74,13 @@ def preprocess(a, ab, ac):
 
 
 def ray_side(o, r):
+    """pl_ray of rt_math.h: the moment in double, rounded once; the bound of |o| and o.r in float32."""
     O, R = o.astype(np.float64), r.astype(np.float64)
     m = np.cross(O, R).astype(F)
-    onorm = np.linalg.norm(O, axis=1).astype(F) * F(1.0001)
-    odr = np.einsum("ij,ij->i", O, R).astype(F)
+    with np.errstate(all="ignore"):
+        s = fma(o[:, 0], o[:, 0], fma(o[:, 1], o[:, 1], o[:, 2] * o[:, 2]))
+        onorm = fma(np.sqrt(s).astype(F), np.full_like(s, F(1.0001)), np.full_like(s, F(1e-18)))
+        odr = fma(o[:, 0], r[:, 0], fma(o[:, 1], r[:, 1], o[:, 2] * r[:, 2]))
     return m, onorm, odr
 
 
