@@ -2269,8 +2269,20 @@ __global__ void __launch_bounds__(256, RT_WAVES_ACC) k_accumulate(ShadeP sp, con
     }
     const float *ts = ts_in + node_base + at;  // slot s of this node: ts[s * ts_stride]
     f3 tmp = mk3(0.0f, 0.0f, 0.0f);
+    // the shadow results of the first lights are asked for together: one memory round trip instead of one per light
+    constexpr int kAhead = 8;
+    float ts_first[kAhead];
+#pragma unroll
+    for (int c = 0; c < kAhead; c++) ts_first[c] = c < sp.nl ? ts[c * ts_stride] : -1.0f;
     for (int c = 0; c < sp.nl; c++) {
-      const float t = ts[c * ts_stride];
+      float t;
+      if (c < kAhead) {
+        t = ts_first[0];
+#pragma unroll
+        for (int q = 1; q < kAhead; q++) t = c == q ? ts_first[q] : t;
+      } else {
+        t = ts[c * ts_stride];
+      }
       if (t >= 0.0f) {
         const LightD L = sp.lights[c];
         const f3 lp = ld3(L.p);
