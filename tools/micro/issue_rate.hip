@@ -20,6 +20,12 @@
                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), \
                  "+s"(s[0]), "+s"(s[1]), "+s"(s[2]), "+s"(s[3]) : "v"(x), "v"(y) : "scc")
 
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+#define P8(b) \
+  asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n" \
+               "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n" \
+               : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "v"(x2), "v"(y2))
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k(float *out, int iters, float x, float y) {
   __shared__ float lds[1024];
@@ -29,7 +35,10 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float x, float y
   lds[threadIdx.x] = x; lds[threadIdx.x + 256] = y;
   __syncthreads();
   float acc = 0.f;
+  v2f_t b[8], x2 = {x, x}, y2 = {y, y};
+  for (int i = 0; i < 8; i++) b[i] = v2f_t{(float)threadIdx.x + i, (float)i};
   for (int it = 0; it < iters; it++) {
+    if (MODE == 5) { P8(b); P8(b); P8(b); P8(b); }                     // 32 packed VALU (64 FMAs per lane)
     if (MODE == 0) { V8(a); V8(a); V8(a); V8(a); }                     // 32 VALU
     if (MODE == 1) { VS8(a, s); VS8(a, s); VS8(a, s); VS8(a, s); }     // 32 VALU + 32 SALU interleaved
     if (MODE == 2) { S8(s); S8(s); S8(s); S8(s); }                     // 32 SALU
@@ -46,7 +55,7 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float x, float y
     }
   }
   float r = acc;
-  for (int i = 0; i < 8; i++) r += a[i];
+  for (int i = 0; i < 8; i++) r += a[i] + b[i].x + b[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = r + s[0] + s[1] + s[2] + s[3];
 }
 
@@ -77,6 +86,7 @@ int main() {
     run<2>("32 SALU", w, d, iters);
     run<3>("32 VALU + 8 ds_read_b128", w, d, iters);
     run<4>("8 ds_read_b128", w, d, iters);
+    run<5>("32 v_pk_fma_f32", w, d, iters);
   }
   return 0;
 }
