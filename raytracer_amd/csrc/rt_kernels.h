@@ -1369,6 +1369,27 @@ RT_D int queue_len(const Ctl *__restrict__ ctl, int level) {
 // non-empty cell.  Every listed triangle of a visited cell is accounted for (tested, or proven irrelevant by
 // the culling), and of equal distances the smallest triangle index wins, as in the reference's scan of its
 // ascending list.
+// A kernel's arguments read again from its argument segment (scalar loads that hit the scalar cache) instead of being
+// held in scalar registers from entry to exit: the walk kernels have more arguments than registers for them, and what
+// does not fit is parked in the lanes of a vector register and fetched back one v_readlane per word and use (in units
+// of the eight-word tuples it was loaded in).  The parts of a ticket outside its cell visits read what they need this
+// way; the opaque pointer keeps every read where it is written.
+#ifndef RT_FRESH_ARGS
+#define RT_FRESH_ARGS 1
+#endif
+template <typename T>
+RT_D T fresh_arg(size_t offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const char __attribute__((address_space(4))) *p = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *reinterpret_cast<const T __attribute__((address_space(4))) *>(p + offset);
+#else
+  (void)offset;
+  return T();  // (the host pass only parses the kernels)
+#endif
+}
+// k_nearest's argument segment: its parameters in order
+struct NearestArgs { GridP g; const Ray *rays; Hit *hits; Ctl *ctl; int level; PrimaryP prim; SplitP split; };
 template <bool COUNT, bool RECTEST>
 __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
                                                  Ctl *__restrict__ ctl, int level, PrimaryP prim, SplitP split) {
@@ -1391,9 +1412,16 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
   Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
   for (;;) {
     uint32_t base;
+#if RT_FRESH_ARGS
+    if (!tickets.take(ticket_counters(fresh_arg<Ctl *>(offsetof(NearestArgs, ctl)), 0, fresh_arg<int>(offsetof(NearestArgs, level))), lane, base)) break;
+#else
     if (!tickets.take(ticket_counters(ctl, 0, level), lane, base)) break;
+#endif
     uint32_t own_sub = 0, own_mask = 0, shared = 0;  // shared = index of the ticket among the shared ones
     if ((base >> 6) >= split_from) {
+#if RT_FRESH_ARGS
+      const SplitP split = fresh_arg<SplitP>(offsetof(NearestArgs, split));
+#endif
       const uint32_t q = (base >> 6) - split_from;
       own_mask = split.ways - 1u; own_sub = q & own_mask; shared = q / split.ways;
       base = 64u * (split_from + shared);
@@ -1402,7 +1430,14 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
     const int idx = base + lane;
     Ray ry;
     ry.i = -2;
-    if (idx < nrays) { if (prim.on) ry = primary_ray(prim, g, idx, true); else ry = rays[idx]; }
+    {  // (the ticket's rays, with its own copies of the arguments)
+#if RT_FRESH_ARGS
+      const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
+      const PrimaryP prim = fresh_arg<PrimaryP>(offsetof(NearestArgs, prim));
+      const Ray *__restrict__ rays = fresh_arg<const Ray *>(offsetof(NearestArgs, rays));
+#endif
+      if (idx < nrays) { if (prim.on) ry = primary_ray(prim, g, idx, true); else ry = rays[idx]; }
+    }
     bool alive = ry.i >= 0;
     if (own_sub == 0u) {  // (a shared ticket's pixels are counted once)
       nPixels += __popcll(__ballot(ry.i != -2));
@@ -1419,6 +1454,10 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
     w.cell = 0;
     uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
     if (alive) {
+#if RT_FRESH_ARGS
+      const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
+      const uint32_t *__restrict__ cstart = g.cell_start;
+#endif
       if (COUNT) nQ++;
       const int glo[3] = {0, 0, 0}, ghi[3] = {g.nv[0] - 1, g.nv[1] - 1, g.nv[2] - 1};
       walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, !COUNT, w);  // (the counting variant reports the reference's step counts)
@@ -1549,6 +1588,10 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
 #endif
       ph.end<7>();
       if (proc) {
+#if RT_FRESH_ARGS
+        const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
+        const uint32_t *__restrict__ cstart = g.cell_start;
+#endif
         if (best_id >= 0) {
           h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v;  // (its voxel: w.cell, where the walk now stays)
           alive = false;
@@ -1562,7 +1605,16 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
       }
       ph.end<6>();
     }
+#if RT_FRESH_ARGS
+    Hit *__restrict__ hits = fresh_arg<Hit *>(offsetof(NearestArgs, hits));
+#endif
     if (own_mask != 0u) {
+#if RT_FRESH_ARGS
+      const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
+      const PrimaryP prim = fresh_arg<PrimaryP>(offsetof(NearestArgs, prim));
+      const Ray *__restrict__ rays = fresh_arg<const Ray *>(offsetof(NearestArgs, rays));
+      const SplitP split = fresh_arg<SplitP>(offsetof(NearestArgs, split));
+#endif
       // A shared ticket.  Every share walked the same cells in the same order and stopped a ray in the first cell in which
       // one of ITS records gave a hit before the cell's exit distance; the reference stops in the first cell in which any
       // record does, and takes the smallest (d, index) there: the smallest (steps, d, index) over the shares.  The key's
@@ -1605,6 +1657,9 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, cons
         nHits += __popcll(__ballot(h.tri >= 0));
       }
     } else {
+#if RT_FRESH_ARGS
+      const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
+#endif
       if (h.tri >= 0) cell_to_voxel(g, w.cell, h.i, h.j, h.k);
       if (idx < nrays) hits[idx] = h;
       nHits += __popcll(__ballot(h.tri >= 0));
@@ -1909,6 +1964,11 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 // The reference's per-triangle shadow cache (voxelize.c:647-655) is scan-order state; it is dropped.
 // ENDS: the bundle of a visit knows that its rays end at their lights (Bundle.re, .T): sharper culling where the rays of
 // a ticket start far apart and meet at the light; where they start on one 8x8 tile it costs more than it saves.
+// k_shadow's argument segment: its parameters in order
+struct ShadowArgs {
+  GridP g; ShadeP sp; const SOrigin *sorg; const int32_t *rand_rank; float *ts_out; long long ts_stride; Ctl *ctl;
+  int level, node_base; SplitP split; const uint32_t *order;
+};
 template <bool COUNT, bool RECTEST, bool ENDS>
 __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const SOrigin *__restrict__ sorg,
                                                 const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
@@ -1934,9 +1994,16 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
   Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
   for (;;) {
     uint32_t base;
+#if RT_FRESH_ARGS
+    if (!tickets.take(ticket_counters(fresh_arg<Ctl *>(offsetof(ShadowArgs, ctl)), 1, fresh_arg<int>(offsetof(ShadowArgs, level))), lane, base)) break;
+#else
     if (!tickets.take(ticket_counters(ctl, 1, level), lane, base)) break;
+#endif
     uint32_t own_sub = 0, own_mask = 0, shared = 0;
     if ((base >> 6) >= split_from) {
+#if RT_FRESH_ARGS
+      const SplitP split = fresh_arg<SplitP>(offsetof(ShadowArgs, split));
+#endif
       const uint32_t q = (base >> 6) - split_from;
       own_mask = split.ways - 1u; own_sub = q & own_mask; shared = q / split.ways;
       base = 64u * (split_from + shared);
@@ -1952,6 +2019,16 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     w.cell = 0;
     uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
     f3 light = mk3(0.0f, 0.0f, 0.0f);  // where this lane's ray ends
+    {  // (the set-up of the ticket's walks, with its own copies of the arguments)
+#if RT_FRESH_ARGS
+    const GridP g = fresh_arg<GridP>(offsetof(ShadowArgs, g));
+    const ShadeP sp = fresh_arg<ShadeP>(offsetof(ShadowArgs, sp));
+    const SOrigin *__restrict__ sorg = fresh_arg<const SOrigin *>(offsetof(ShadowArgs, sorg));
+    const int32_t *__restrict__ rand_rank = fresh_arg<const int32_t *>(offsetof(ShadowArgs, rand_rank));
+    const uint32_t *__restrict__ order = fresh_arg<const uint32_t *>(offsetof(ShadowArgs, order));
+    const int node_base = fresh_arg<int>(offsetof(ShadowArgs, node_base));
+    const uint32_t *__restrict__ cstart = g.cell_start;
+#endif
     if (item < total) {
       // slot = item / n: one division per wavefront; its 64 items span at most two slots unless the queue is tiny
       const uint32_t slot0 = base / (uint32_t)n, rest = base - slot0 * (uint32_t)n + (uint32_t)lane;
@@ -1998,6 +2075,7 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
     if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
       mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
       if (COUNT) nT += mycnt;
+    }
     }
     // The ticket's walks as the fan of one point light, if they all end at the same one (tickets that are a tile's hit
     // points, in the kernels built without ENDS, i.e. for scenes without secondary rays: with the fan compiled into ulica's
@@ -2152,6 +2230,10 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
 #endif
       ph.end<7>();
       if (proc && alive) {
+#if RT_FRESH_ARGS
+        const GridP g = fresh_arg<GridP>(offsetof(ShadowArgs, g));
+        const uint32_t *__restrict__ cstart = g.cell_start;
+#endif
         alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
         if (alive) {
           mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
@@ -2160,7 +2242,14 @@ __global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, co
       }
       ph.end<6>();
     }
+#if RT_FRESH_ARGS
+    float *__restrict__ ts_out = fresh_arg<float *>(offsetof(ShadowArgs, ts_out));
+    const long long ts_stride = fresh_arg<long long>(offsetof(ShadowArgs, ts_stride));
+#endif
     if (own_mask != 0u) {
+#if RT_FRESH_ARGS
+      const SplitP split = fresh_arg<SplitP>(offsetof(ShadowArgs, split));
+#endif
       // A shared ticket (no transparent triangle in the scene, so ts stays 1): a ray is in shadow if any share found a
       // blocker.  The shares OR their blocked rays into the ticket's mask; the one that finishes last writes the results.
       unsigned long long *mask = split.slots + shared;
