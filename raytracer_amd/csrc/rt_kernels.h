@@ -1388,11 +1388,17 @@ RT_D T fresh_arg(size_t offset) {
   return T();  // (the host pass only parses the kernels)
 #endif
 }
-// k_nearest's argument segment: its parameters in order
+// k_nearest's arguments: one structure, so that a member's offset in it is its offset in the argument segment
 struct NearestArgs { GridP g; const Ray *rays; Hit *hits; Ctl *ctl; int level; PrimaryP prim; SplitP split; };
 template <bool COUNT, bool RECTEST>
-__global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(GridP g, const Ray *__restrict__ rays, Hit *__restrict__ hits,
-                                                 Ctl *__restrict__ ctl, int level, PrimaryP prim, SplitP split) {
+__global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs args) {
+  const GridP &g = args.g;
+  const Ray *__restrict__ rays = args.rays;
+  Hit *__restrict__ hits = args.hits;
+  Ctl *__restrict__ ctl = args.ctl;
+  const int level = args.level;
+  const PrimaryP &prim = args.prim;
+  const SplitP &split = args.split;
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
@@ -1964,16 +1970,23 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 // The reference's per-triangle shadow cache (voxelize.c:647-655) is scan-order state; it is dropped.
 // ENDS: the bundle of a visit knows that its rays end at their lights (Bundle.re, .T): sharper culling where the rays of
 // a ticket start far apart and meet at the light; where they start on one 8x8 tile it costs more than it saves.
-// k_shadow's argument segment: its parameters in order
+// k_shadow's arguments (one structure, like NearestArgs)
 struct ShadowArgs {
   GridP g; ShadeP sp; const SOrigin *sorg; const int32_t *rand_rank; float *ts_out; long long ts_stride; Ctl *ctl;
   int level, node_base; SplitP split; const uint32_t *order;
 };
 template <bool COUNT, bool RECTEST, bool ENDS>
-__global__ void __launch_bounds__(256, RT_WAVES) k_shadow(GridP g, ShadeP sp, const SOrigin *__restrict__ sorg,
-                                                const int32_t *__restrict__ rand_rank, float *__restrict__ ts_out,
-                                                long long ts_stride, Ctl *__restrict__ ctl, int level, int node_base, SplitP split,
-                                                const uint32_t *__restrict__ order) {
+__global__ void __launch_bounds__(256, RT_WAVES) k_shadow(ShadowArgs args) {
+  const GridP &g = args.g;
+  const ShadeP &sp = args.sp;
+  const SOrigin *__restrict__ sorg = args.sorg;
+  const int32_t *__restrict__ rand_rank = args.rand_rank;
+  float *__restrict__ ts_out = args.ts_out;
+  const long long ts_stride = args.ts_stride;
+  Ctl *__restrict__ ctl = args.ctl;
+  const int level = args.level, node_base = args.node_base;
+  const SplitP &split = args.split;
+  const uint32_t *__restrict__ order = args.order;
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];

@@ -785,8 +785,9 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
     {
       Span sp(c, W_NEAREST);
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
+      const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split};
 #define RT_LAUNCH_NEAREST(COUNT, RECTEST) \
-  KLAUNCH(c, (k_nearest<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split)
+  KLAUNCH(c, (k_nearest<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, nargs)
       if (c->opt_count) { if (rectest) RT_LAUNCH_NEAREST(true, true); else RT_LAUNCH_NEAREST(true, false); }
       else { if (rectest) RT_LAUNCH_NEAREST(false, true); else RT_LAUNCH_NEAREST(false, false); }
 #undef RT_LAUNCH_NEAREST
@@ -872,8 +873,9 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       }
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
+      const ShadowArgs sargs{c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split, order};
 #define RT_LAUNCH_SHADOW(COUNT, RECTEST, ENDS) \
-  KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split, order)
+  KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, sargs)
 #define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)
       const bool ends = c->opt_bundle_ends < 0 ? c->levels > 1 : c->opt_bundle_ends != 0;
       if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW2(true, true); else RT_LAUNCH_SHADOW2(true, false); }
