@@ -126,6 +126,31 @@ def test_tonemap_matches_oracle_bytes(renderer, gamma):
     assert np.array_equal(rgba_to_u8(rgba), rgba_to_u8(want))
 
 
+@pytest.mark.parametrize("gamma", [2.5, 0.5, 1.5, 3.0, 4.0])
+def test_tonemap_next_to_the_rounding_boundaries(renderer, gamma):
+    # A ramp over [0, 1] plus, for every byte b, the binary32 values around (b / 255) ** (1 / gamma): where the short
+    # forms of the power (binary32, then double) must hand over to pow.  min = 0 and max = 1 exactly, so x is the input.
+    rng = np.random.default_rng(7)
+    edges = (np.arange(1, 256, dtype=np.float64) / 255.0) ** (1.0 / gamma)
+    vals = []
+    for e in edges:
+        v = np.float32(e)
+        for _ in range(4):
+            v = np.nextafter(v, np.float32(0.0))
+        for _ in range(9):
+            vals.append(v)
+            v = np.nextafter(v, np.float32(2.0))
+    vals = np.array(vals, np.float32)
+    ramp = np.linspace(0.0, 1.0, 3 * 256 * 341 - vals.size, dtype=np.float32)
+    allv = np.concatenate([vals, rng.permutation(ramp)])
+    allv[0], allv[-1] = 0.0, 1.0
+    rgb = np.ascontiguousarray(allv.reshape(341, 256, 3))
+    mm = np.array([0, 0, 0, 1, 1, 1], np.float32)
+    rgba = renderer.tonemap_host(rgb, mm, gamma)
+    want = O.tonemap(rgb, mm, gamma)
+    assert np.array_equal(rgba_to_u8(rgba), rgba_to_u8(want))
+
+
 def test_counters_match_oracle(renderer):
     z, prefix, over = load_case("s3")
     h, w = z["ids"].shape
