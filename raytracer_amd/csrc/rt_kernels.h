@@ -26,6 +26,9 @@
 #ifndef RT_WAVES_ACC
 #define RT_WAVES_ACC 4  // k_accumulate: 128 instead of 131 registers buy a fourth wave per SIMD (0.27 -> 0.23 ms); five spill (0.51 ms)
 #endif
+#ifndef RT_WAVES_ACC_PLAIN
+#define RT_WAVES_ACC_PLAIN 8  // k_accumulate without the specular term's pow (scenes without a surface with ks > 0): 62 registers
+#endif
 #ifndef RT_WAVES_HIT
 #define RT_WAVES_HIT 4  // k_hit: five waves per SIMD spill (0.14 -> 0.28 ms)
 #endif
@@ -2318,13 +2321,15 @@ RT_D void mm_fold(float *mn, float *mx, const float *omn, const float *omx) {
 }
 
 // One light's contribution (raytrace.c:217-235 / 271-289).
+// SPECULAR = false: for scenes none of whose surfaces has ks > 0 (the pow of the specular term and its registers are compiled out)
+template <bool SPECULAR>
 RT_D f3 light_term(const SurfaceD &sf, f3 norm, f3 r, f3 rnew, f3 onew, f3 lpos, float lflux, f3 lcol, f3 nc,
                    float ts, float distmod) {
   float ndl = dot3(norm, rnew);
   float df = sf.kd * ndl;
   if (df < 0.0f && sf.kt > 0.0f) df = -df;
   float rf = 0.0f;
-  if (sf.ks > 0.0f) {
+  if (SPECULAR && sf.ks > 0.0f) {
     f3 t = reflect3(norm, rnew, ndl);
     rf = (float)((double)sf.ks * pow((double)dot3(r, t), (double)sf.g));
     if (rf < 0.0f && sf.kt > 0.0f) rf = -rf;
@@ -2338,7 +2343,8 @@ RT_D f3 light_term(const SurfaceD &sf, f3 norm, f3 r, f3 rnew, f3 onew, f3 lpos,
 // ambient, + kr * reflected child, + kt * refracted child, + point lights in order, + planar lights
 // (16 samples each, accumulated exactly as written, quirks included).  Levels run deepest first so a
 // node finds its children's colours ready.  Level 0 also writes the tile-major framebuffer.
-__global__ void __launch_bounds__(256, RT_WAVES_ACC) k_accumulate(ShadeP sp, const Ray *__restrict__ rays, const Node *__restrict__ nodes,
+template <bool SPECULAR>
+__global__ void __launch_bounds__(256, SPECULAR ? RT_WAVES_ACC : RT_WAVES_ACC_PLAIN) k_accumulate(ShadeP sp, const Ray *__restrict__ rays, const Node *__restrict__ nodes,
                                                     const float *__restrict__ ts_in, long long ts_stride, const int32_t *__restrict__ rand_rank,
                                                     float *__restrict__ colors, Ctl *__restrict__ ctl, int level,
                                                     int node_base, float *__restrict__ fb_rgb, int32_t *__restrict__ fb_ids,
@@ -2388,7 +2394,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_ACC) k_accumulate(ShadeP sp, con
       if (t >= 0.0f) {
         const LightD L = sp.lights[c];
         const f3 lp = ld3(L.p);
-        tmp = light_term(sf, norm, r, ray3(onew, lp), onew, lp, L.flux, ld3(L.color), nc, t, sp.distmod);
+        tmp = light_term<SPECULAR>(sf, norm, r, ray3(onew, lp), onew, lp, L.flux, ld3(L.color), nc, t, sp.distmod);
         res = add3(res, tmp);
       }
     }
@@ -2400,7 +2406,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_ACC) k_accumulate(ShadeP sp, con
         if (t >= 0.0f) {
           f3 lp, lcol; float lflux;
           slot_light(sp, slot, rand_rank[gidx], lp, lflux, lcol);
-          sum = light_term(sf, norm, r, ray3(onew, lp), onew, lp, lflux, lcol, nc, t, sp.distmod);
+          sum = light_term<SPECULAR>(sf, norm, r, ray3(onew, lp), onew, lp, lflux, lcol, nc, t, sp.distmod);
         }
         sum = mul3(sum, 1.0f / kPlanarSamples);
         tmp = add3(tmp, sum);

@@ -118,6 +118,7 @@ struct rtgpu_ctx {
   int opt_record_test = 1;  // option "record_test": the bundle's record-level test in the walk kernels
   int opt_bundle_ends = -1;  // option "bundle_ends": the shadow walk's bundles narrow towards their lights; -1: in scenes with secondary rays
   bool mostly_opaque = true;  // fewer than half of the scene's triangles are transparent (kt > 0)
+  bool any_specular = true;   // some surface a triangle uses has ks > 0 (k_accumulate's variant)
   int opt_split = 0;  // option "split": 0 never, 1 as the queue length suggests, 2 / 4: every ticket, that many ways
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
   PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
@@ -537,6 +538,8 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
     c->fan = f > c->fan ? f : c->fan;
   }
   c->levels = c->fan > 0 ? kMaxLevels : 1;
+  c->any_specular = false;
+  for (int q = 0; q < s->ns; q++) if (used[q] && s->surfaces[q].ks > 0.0f) c->any_specular = true;
   // Scenes of mostly transparent triangles keep their cells' lists in ascending order (the transparency product is
   // taken in list order) and their shadow rays leave scattered points: bundles are wide against the triangles there.
   size_t transparent = 0;
@@ -889,10 +892,13 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   for (int L = c->levels - 1; L >= 0; L--) {
     Span sp(c, W_ACCUM);
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-    KLAUNCH(c, k_accumulate, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->shade, c->d_rays[L], c->d_nodes,
-                       c->d_ts, (long long)c->total_nodes, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels,
-                       L == 0 ? c->d_partial : nullptr,  // level 0 (the last one) also folds the colour range of its blocks
-                       L == 0 ? c->prim : queued, level_order(c, L));
+#define RT_LAUNCH_ACCUMULATE(SPECULAR) \
+    KLAUNCH(c, (k_accumulate<SPECULAR>), dim3(node_blocks(capL, L)), dim3(256), c->stream, c->shade, c->d_rays[L], c->d_nodes, \
+                       c->d_ts, (long long)c->total_nodes, c->d_rank, c->d_colors, c->d_ctl, L, (int)c->base[L], d_rgb, d_ids, (long long)t0 * kTilePixels, \
+                       L == 0 ? c->d_partial : nullptr,  /* level 0 (the last one) also folds the colour range of its blocks */ \
+                       L == 0 ? c->prim : queued, level_order(c, L))
+    if (c->any_specular) RT_LAUNCH_ACCUMULATE(true); else RT_LAUNCH_ACCUMULATE(false);
+#undef RT_LAUNCH_ACCUMULATE
   }
   {
     Span sp(c, W_MINMAX);
