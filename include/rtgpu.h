@@ -156,6 +156,8 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * before they stage the batch, or do not; -1: only unless half of the scene's triangles or more are transparent; same image),
  * "bundle_ends" (default -1: in scenes with reflective or transparent surfaces; 1 / 0: the shadow walk's culling knows, or does
  * not, that a wavefront's shadow rays end at their lights and come closer together on the way; same image),
+ * "fuse_hit" (default 1: a recursion level that neither spawns rays nor meets a textured triangle shades its hits at the end
+ * of the nearest-hit walk, so that the hit records do not go through memory; 0: always in a kernel of its own; same image),
  * "filter" (default 1; 0 switches off the conservative triangle filter and the batch culling of the
  * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */
 int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);

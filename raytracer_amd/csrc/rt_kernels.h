@@ -1372,6 +1372,23 @@ RT_D int queue_len(const Ctl *__restrict__ ctl, int level) {
 // non-empty cell.  Every listed triangle of a visited cell is accounted for (tested, or proven irrelevant by
 // the culling), and of equal distances the smallest triangle index wins, as in the reference's scan of its
 // ascending list.
+// The shaded hit of a ray without its texture and its secondary rays (raytrace.c:170-182): hit point, the normal turned
+// against the ray, the surface's colour.  A miss keeps its marker (h.tri < 0) and zeros.  k_hit, and the nearest-hit walk
+// itself where a level neither spawns rays nor meets a textured triangle.
+RT_D Node plain_node(const ShadeP &sp, const Hit &h, f3 o, f3 r, int &sid) {
+  Node nd;
+  nd.tri = h.tri; nd.refl = -1; nd.refr = -1;
+  nd.p[0] = nd.p[1] = nd.p[2] = 0.0f; nd.n[0] = nd.n[1] = nd.n[2] = 0.0f; nd.c[0] = nd.c[1] = nd.c[2] = 0.0f;
+  sid = -1;
+  if (h.tri >= 0) {
+    const f3 onew = raypoint3(o, r, h.d);  // voxelize.c:587
+    f3 norm = ld3(sp.tri_aux + 4 * h.tri);
+    if (dot3(r, norm) > 0.0f) norm = neg3(norm);  // raytrace.c:175-178
+    sid = sp.tri_sid[h.tri];
+    st3(nd.p, onew); st3(nd.n, norm); st3(nd.c, ld3(sp.surf[sid].color));
+  }
+  return nd;
+}
 // A kernel's arguments read again from its argument segment (scalar loads that hit the scalar cache) instead of being
 // held in scalar registers from entry to exit: the walk kernels have more arguments than registers for them, and what
 // does not fit is parked in the lanes of a vector register and fetched back one v_readlane per word and use (in units
@@ -1392,8 +1409,11 @@ RT_D T fresh_arg(size_t offset) {
 #endif
 }
 // k_nearest's arguments: one structure, so that a member's offset in it is its offset in the argument segment
-struct NearestArgs { GridP g; const Ray *rays; Hit *hits; Ctl *ctl; int level; PrimaryP prim; SplitP split; };
-template <bool COUNT, bool RECTEST>
+struct NearestArgs {
+  GridP g; const Ray *rays; Hit *hits; Ctl *ctl; int level; PrimaryP prim; SplitP split;
+  ShadeP sp; Node *nodes; SOrigin *sorg; int node_base;  // for the instances that shade their hits themselves (FUSE)
+};
+template <bool COUNT, bool RECTEST, bool FUSE>
 __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs args) {
   const GridP &g = args.g;
   const Ray *__restrict__ rays = args.rays;
@@ -1617,6 +1637,25 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
 #if RT_FRESH_ARGS
     Hit *__restrict__ hits = fresh_arg<Hit *>(offsetof(NearestArgs, hits));
 #endif
+    // the ray's result: its hit record for k_hit, or (FUSE) the shaded hit and the origin of its shadow walks themselves
+    auto emit = [&](const Hit &hh, Hit *__restrict__ out) {
+      if (FUSE) {
+        const ShadeP fsp = fresh_arg<ShadeP>(offsetof(NearestArgs, sp));
+        Node *__restrict__ nodes = fresh_arg<Node *>(offsetof(NearestArgs, nodes));
+        SOrigin *__restrict__ sorg = fresh_arg<SOrigin *>(offsetof(NearestArgs, sorg));
+        const int node_base = fresh_arg<int>(offsetof(NearestArgs, node_base));
+        if (idx < nrays) {
+          int sid;
+          const Node nd = plain_node(fsp, hh, o, r, sid);
+          nodes[node_base + idx] = nd;
+          SOrigin so;
+          so.p[0] = nd.p[0]; so.p[1] = nd.p[1]; so.p[2] = nd.p[2]; so.tri = nd.tri;
+          sorg[node_base + idx] = so;
+        }
+      } else if (idx < nrays) {
+        out[idx] = hh;
+      }
+    };
     if (own_mask != 0u) {
 #if RT_FRESH_ARGS
       const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
@@ -1662,15 +1701,15 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
           for (int q = (int)(k >> 54); q > 0; q--) (void)walk_step(g, r, w2);
           cell_to_voxel(g, w2.cell, h.i, h.j, h.k);
         }
-        if (idx < nrays) hits[idx] = h;
+        emit(h, hits);
         nHits += __popcll(__ballot(h.tri >= 0));
       }
     } else {
 #if RT_FRESH_ARGS
       const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
 #endif
-      if (h.tri >= 0) cell_to_voxel(g, w.cell, h.i, h.j, h.k);
-      if (idx < nrays) hits[idx] = h;
+      if (!FUSE && h.tri >= 0) cell_to_voxel(g, w.cell, h.i, h.j, h.k);
+      emit(h, hits);
       nHits += __popcll(__ballot(h.tri >= 0));
     }
     RT_TICKET(ph.end<0>(); if (level == 0) tl.end(0, base, lane, ph); busy += __builtin_amdgcn_s_memtime() - tl.t0;)
@@ -1816,24 +1855,22 @@ __global__ void __launch_bounds__(256, RT_WAVES_HIT) k_hit(GridP g, ShadeP sp, c
   Hit h; h.tri = -2;
   Ray ry;
   if (valid) { h = hits[idx]; if (prim.on) ry = primary_ray(prim, g, idx, false); else ry = rays[idx]; }
-  Node nd;
-  nd.tri = h.tri; nd.refl = -1; nd.refr = -1;
-  nd.p[0] = nd.p[1] = nd.p[2] = 0.0f; nd.n[0] = nd.n[1] = nd.n[2] = 0.0f; nd.c[0] = nd.c[1] = nd.c[2] = 0.0f;
+  int sid;
+  Node nd = plain_node(sp, h, ld3(ry.o), ld3(ry.r), sid);
   bool want_refl = false, want_refr = false;
   f3 refl_dir = mk3(0, 0, 0), refr_dir = mk3(0, 0, 0);
   if (h.tri >= 0) {
-    const f3 o = ld3(ry.o), r = ld3(ry.r);
-    const f3 onew = raypoint3(o, r, h.d);  // voxelize.c:587
-    f3 norm = ld3(sp.tri_aux + 4 * h.tri);
-    if (dot3(r, norm) > 0.0f) norm = neg3(norm);  // raytrace.c:175-178
-    const int sid = sp.tri_sid[h.tri];
+    const f3 r = ld3(ry.r);
     const SurfaceD sf = sp.surf[sid];
-    f3 nc = ld3(sf.color);
+    f3 norm = ld3(nd.n);
     if (sid == 7) {  // raytrace.c:183
       int slot = h.tri == sp.tex_tri[0] ? 0 : h.tri == sp.tex_tri[1] ? 1 : h.tri == sp.tex_tri[2] ? 2 : h.tri == sp.tex_tri[3] ? 3 : -1;
-      if (slot >= 0) apply_texture(slot, ld3(geom + 9 * h.tri + 3), ld3(geom + 9 * h.tri + 6), h.u, h.v, norm, nc);
+      if (slot >= 0) {
+        f3 nc = ld3(nd.c);
+        apply_texture(slot, ld3(geom + 9 * h.tri + 3), ld3(geom + 9 * h.tri + 6), h.u, h.v, norm, nc);
+        st3(nd.n, norm); st3(nd.c, nc);
+      }
     }
-    st3(nd.p, onew); st3(nd.n, norm); st3(nd.c, nc);
     if (spawn) {
       const f3 inv = neg3(r);
       if (sf.kr > 0.0f) { want_refl = true; refl_dir = reflect3(norm, inv, dot3(norm, inv)); }

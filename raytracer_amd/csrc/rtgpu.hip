@@ -116,6 +116,7 @@ struct rtgpu_ctx {
   uint32_t *d_split_done_n = nullptr, *d_split_done_s = nullptr;
   int opt_split_kernels = 3;  // option "split_kernels": bit 0 nearest walk, bit 1 shadow walk (diagnostic)
   int opt_record_test = 1;  // option "record_test": the bundle's record-level test in the walk kernels
+  bool opt_fuse_hit = true; // option "fuse_hit": the nearest-hit walk shades its own hits where it can
   int opt_bundle_ends = -1;  // option "bundle_ends": the shadow walk's bundles narrow towards their lights; -1: in scenes with secondary rays
   bool mostly_opaque = true;  // fewer than half of the scene's triangles are transparent (kt > 0)
   bool any_specular = true;   // some surface a triangle uses has ks > 0 (k_accumulate's variant)
@@ -476,6 +477,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "chunk_bytes")) { if (value < (1 << 20)) return fail(c, RTGPU_E_INVALID_PARAM, "chunk_bytes < 1 MiB"); c->chunk_bytes = value; c->chunk_tiles_cap = 0; }
   else if (!strcmp(name, "filter")) c->filter = value != 0;
   else if (!strcmp(name, "record_test")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "record_test: -1 (by the scene), 0 or 1"); c->opt_record_test = (int)value; }
+  else if (!strcmp(name, "fuse_hit")) c->opt_fuse_hit = value != 0;
   else if (!strcmp(name, "bundle_ends")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "bundle_ends: -1 (by the scene), 0 or 1"); c->opt_bundle_ends = (int)value; }
   else if (!strcmp(name, "order")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "order: 0, 1 or 2"); if ((int)value != c->opt_order) c->chunk_tiles_cap = 0; c->opt_order = (int)value; }
   else if (!strcmp(name, "order_parts")) { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RTGPU_E_INVALID_PARAM, "order_parts: 1, 2, 4 or 8"); c->opt_order_parts = (int)value; }
@@ -785,17 +787,24 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
         HIPCHK(c, hipMemsetAsync(c->d_split_done_n, 0, sizeof(uint32_t) * shared, c->stream));
       }
     }
+    bool fused = false;
     {
       Span sp(c, W_NEAREST);
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
-      const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split};
-#define RT_LAUNCH_NEAREST(COUNT, RECTEST) \
-  KLAUNCH(c, (k_nearest<COUNT, RECTEST>), dim3(pgrid), dim3(256), c->stream, nargs)
-      if (c->opt_count) { if (rectest) RT_LAUNCH_NEAREST(true, true); else RT_LAUNCH_NEAREST(true, false); }
-      else { if (rectest) RT_LAUNCH_NEAREST(false, true); else RT_LAUNCH_NEAREST(false, false); }
+      // A level that neither spawns rays nor meets a textured triangle shades its hits at the end of the walk: the hit
+      // records do not go through memory and k_hit is not launched (option "fuse_hit").
+      fused = c->opt_fuse_hit && !(L + 1 < c->levels) && c->tex_tri[0] < 0 && c->tex_tri[1] < 0 && c->tex_tri[2] < 0 && c->tex_tri[3] < 0;
+      const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split,
+                              c->shade, c->d_nodes, c->d_sorg, (int)c->base[L]};
+#define RT_LAUNCH_NEAREST(COUNT, RECTEST, FUSE) \
+  KLAUNCH(c, (k_nearest<COUNT, RECTEST, FUSE>), dim3(pgrid), dim3(256), c->stream, nargs)
+#define RT_LAUNCH_NEAREST2(COUNT, RECTEST) do { if (fused) RT_LAUNCH_NEAREST(COUNT, RECTEST, true); else RT_LAUNCH_NEAREST(COUNT, RECTEST, false); } while (0)
+      if (c->opt_count) { if (rectest) RT_LAUNCH_NEAREST2(true, true); else RT_LAUNCH_NEAREST2(true, false); }
+      else { if (rectest) RT_LAUNCH_NEAREST2(false, true); else RT_LAUNCH_NEAREST2(false, false); }
+#undef RT_LAUNCH_NEAREST2
 #undef RT_LAUNCH_NEAREST
     }
-    {
+    if (!fused) {
       Span sp(c, W_HIT);
       const bool spawn = L + 1 < c->levels;
       KLAUNCH(c, k_hit, dim3(node_blocks(capL, L)), dim3(256), c->stream, c->grid, c->shade, c->d_rays[L], c->d_hits,

@@ -90,6 +90,26 @@ def test_record_level_bundle_test_does_not_change_the_frame(renderer, prefix, ov
     assert frames[3][1]["shadow_lane_slots"] <= frames[4][1]["shadow_lane_slots"]
 
 
+@pytest.mark.parametrize("prefix,over,w,h,tex", CASES, ids=[c[0].split("/")[1] + ("_glass" if c[1] and "pokoj" in str(c[1]) else "") + "_%dx%d" % (c[2], c[3]) for c in CASES])
+def test_hits_shaded_by_the_walk_itself_give_the_same_frame(renderer, prefix, over, w, h, tex):
+    """Option "fuse_hit": a level that neither spawns rays nor meets a textured triangle shades its hits at the end of the
+    nearest-hit walk (1, the default) or in k_hit like every other level (0).  Same frame, bit for bit, same counters."""
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    scene = rt.Scene(os.path.join(ROOT, prefix), texture=tex, width=w, height=h, **over)
+    try:
+        renderer.set_option("fuse_hit", 1)
+        a, ca = frame(renderer, scene, 1, count=True)
+        renderer.set_option("fuse_hit", 0)
+        b, cb = frame(renderer, scene, 1, count=True)
+    finally:
+        renderer.set_option("fuse_hit", 1)
+    assert np.array_equal(a["ids"], b["ids"])
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert np.array_equal(a["minmax"].view(np.uint32), b["minmax"].view(np.uint32))
+    for k in ("nearest_queries", "shadow_queries", "nearest_steps", "nearest_tests", "shadow_steps", "shadow_tests"):
+        assert ca[k] == cb[k], k
+
+
 def test_filter_counters(renderer):
     scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=320, height=180)
     _, on = frame(renderer, scene, 1, count=True)
