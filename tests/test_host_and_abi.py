@@ -208,7 +208,7 @@ def test_tile_plan_of_the_c_multi_gpu_host(w, h):
 
 
 def test_integration_md_shows_the_stub_that_is_compiled():
-    """INTEGRATION.md prints integration/raytrace_gpu.c, the file that oracle/Makefile compiles against the reference's
-    headers: the printed text is the file, not a sketch of it."""
+    """The integration guide prints integration/raytrace_gpu.c, the file that oracle/Makefile compiles against the
+    reference's headers: the printed text is the file, not a sketch of it."""
     stub = open(os.path.join(ROOT, "integration", "raytrace_gpu.c")).read()
     assert stub in open(os.path.join(ROOT, "INTEGRATION.md")).read()
