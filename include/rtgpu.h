@@ -142,7 +142,7 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
 
 /* Options: "count" (0/1) S/T counters, "timing" (0/1/2) per-kernel events (2: walk kernels only), "chunk_bytes" (device
  * memory budget of the ray/node queues, default 8 GiB), "waves_per_cu" (persistent grid size; 0 = the default:
- * what each walk kernel is compiled for, 20 and 24), "pipeline" (default 1: rtgpu_frame_begin builds on its
+ * what each walk kernel is compiled for, 20, and 24 or 28), "pipeline" (default 1: rtgpu_frame_begin builds on its
  * own stream into the buffers the previous frame does not use, overlapping that frame's kernels; 0: on the context's stream),
  * "queue_sizing" (default 1: in scenes with reflective or transparent surfaces the queues of the secondary rays are sized from
  * what the scene's chunks produce, which costs one host synchronisation per chunk, and a chunk whose queues turn out too small

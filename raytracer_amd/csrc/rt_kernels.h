@@ -35,6 +35,9 @@
 #ifndef RT_WAVES
 #define RT_WAVES 6  // waves per SIMD the shadow walk is compiled for (80 VGPRs; with 8 and 64 VGPRs it spills and runs 6 % slower)
 #endif
+#ifndef RT_WAVES_ENDS
+#define RT_WAVES_ENDS 7  // ... and its instances for rays that end at their lights (scenes with secondary rays): ulica 1080p 105 -> 101 ms with seven (72 VGPRs), where temple's instance loses 6 %
+#endif
 #ifndef RT_WAVES_NEAREST
 #define RT_WAVES_NEAREST 5  // ... and the nearest-hit walk: it keeps more per ray (the best hit), 96 VGPRs hold it without spills (4 % faster than 6 waves)
 #endif
@@ -2016,7 +2019,7 @@ struct ShadowArgs {
   int level, node_base; SplitP split; const uint32_t *order;
 };
 template <bool COUNT, bool RECTEST, bool ENDS>
-__global__ void __launch_bounds__(256, RT_WAVES) k_shadow(ShadowArgs args) {
+__global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow(ShadowArgs args) {
   const GridP &g = args.g;
   const ShadeP &sp = args.sp;
   const SOrigin *__restrict__ sorg = args.sorg;

@@ -857,7 +857,8 @@ const uint32_t *level_order(const rtgpu_ctx *c, int L) {
 // Second half: shadow walks, colours deepest level first, colour range, statistics.
 int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d_ids, float *d_minmax) {
   const int n0 = nt_chunk * kTilePixels;
-  const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * RT_WAVES) + 3) / 4);
+  const bool ends = c->opt_bundle_ends < 0 ? c->levels > 1 : c->opt_bundle_ends != 0;
+  const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * (ends ? RT_WAVES_ENDS : RT_WAVES)) + 3) / 4);
   if (c->shade.nslots > 0) {
     for (int L = 0; L < c->levels; L++) {
       SplitP split{0xffffffffu, 1u, c->d_split_masks, c->d_split_done_s};
@@ -889,7 +890,6 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
 #define RT_LAUNCH_SHADOW(COUNT, RECTEST, ENDS) \
   KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, sargs)
 #define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)
-      const bool ends = c->opt_bundle_ends < 0 ? c->levels > 1 : c->opt_bundle_ends != 0;
       if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW2(true, true); else RT_LAUNCH_SHADOW2(true, false); }
       else { if (rectest) RT_LAUNCH_SHADOW2(false, true); else RT_LAUNCH_SHADOW2(false, false); }
 #undef RT_LAUNCH_SHADOW2
