@@ -16,6 +16,7 @@
 #ifndef RTGPU_H
 #define RTGPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -162,7 +163,8 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */
 int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);
 
-/* Copies the scene to the GPU (replaces RT_Scene as the renderer's input). */
+/* Copies the scene to the GPU (replaces RT_Scene as the renderer's input).  A scene equal in every array and parameter to
+ * the one the context already holds is recognised (the context keeps a host copy to compare with) and costs a comparison. */
 int rtgpu_scene_upload(rtgpu_ctx *ctx, const rtgpu_scene_desc *scene);
 
 /* Everything rtVisualizedSceneRaytrace does before its pixel loop (src/raytrace.c:341-366):
@@ -223,6 +225,13 @@ int rtgpu_render_shade(rtgpu_ctx *ctx, const int32_t *d_all_counts, int64_t per_
 int rtgpu_tonemap(rtgpu_ctx *ctx, const float *d_rgb, int64_t npixels, const float *d_minmax, float gamma,
                   uint32_t *d_rgba);
 
+/* The same with the zero-terminated gamma list rtVisualizedSceneToBitmap takes as its param1 (src/raytrace.c:439-447),
+ * given as ngammas gammas in HOST memory (read before the call returns): per channel the powers are summed in list order
+ * as src/raytrace.c:456-460 sums them and divided by (float)ngammas (src/raytrace.c:462-466).  ngammas = 1 is
+ * rtgpu_tonemap; ngammas = 0, the reference's empty list, gives 0 / 0 = NaN per channel, i.e. black pixels. */
+int rtgpu_tonemap_multi(rtgpu_ctx *ctx, const float *d_rgb, int64_t npixels, const float *d_minmax, const float *gammas,
+                        int32_t ngammas, uint32_t *d_rgba);
+
 /* De-interleaves tile-major data gathered from all ranks (rank r's block first, each block
  * rtgpu_tile_count(r)*64 elements of elem_bytes) into a row-major w*h image. */
 int rtgpu_untile(rtgpu_ctx *ctx, const void *d_gathered, int world, int elem_bytes, void *d_image);
@@ -262,6 +271,37 @@ int rtgpu_render_host(rtgpu_ctx *ctx, float *rgb, int32_t *ids, float *minmax);
 /* Host-array form of rtgpu_tonemap (row-major in, row-major out). */
 int rtgpu_tonemap_host(rtgpu_ctx *ctx, const float *rgb, int64_t npixels, const float *minmax, float gamma,
                        uint32_t *rgba);
+
+/* Host-array form of rtgpu_tonemap_multi. */
+int rtgpu_tonemap_multi_host(rtgpu_ctx *ctx, const float *rgb, int64_t npixels, const float *minmax, const float *gammas,
+                             int32_t ngammas, uint32_t *rgba);
+
+/* The drop-in form of the frame for a C host that keeps the reference's result type: the frame's pixels arrive in the
+ * caller's own records, RT_VisualizedScenePixel of src/raytrace.h:23-27 (RT_Color c; RT_Triangle *t), as
+ * rtVisualizedSceneSetPixel fills them (src/raytrace.c:402), row-major, map[y * w + x] (src/raytrace.h:41-50).
+ * The layout is described, not assumed: stride = sizeof of a record, color_offset = offset of the four colour floats,
+ * tri_offset = offset of the triangle pointer (-1: no such member), tri_base = the address of scene->t[0] and tri_stride
+ * = sizeof(RT_Triangle) in the CALLER's address space: the pointer of a pixel is tri_base + id * tri_stride, NULL without
+ * a primary hit; the library computes it as a number and never follows it.  The colour's fourth float and the bytes of
+ * a record that neither member covers are 0; pixels whose ray never entered the grid, which the reference leaves
+ * unwritten (src/raytrace.c:381-382), are all zero. */
+typedef struct rtgpu_pixel_layout {
+  int64_t stride, color_offset, tri_offset;
+  uint64_t tri_base;
+  int64_t tri_stride;
+} rtgpu_pixel_layout;
+/* rtgpu_frame_begin must have been called.  Renders all tiles on this context's GPU and writes width * height records
+ * to `map` (host memory; page-locked memory from rtgpu_pinned_alloc is filled at the full rate of the host link, about
+ * four times as fast as pageable memory) and the colour range to minmax[6] (may be NULL).  Returns when both are there. */
+int rtgpu_render_pixelmap(rtgpu_ctx *ctx, void *map, const rtgpu_pixel_layout *layout, float *minmax);
+/* rtVisualizedSceneToBitmap (src/raytrace.c:424-472) on such records: npixels records of `map`, the frame's colour range
+ * (RT_VisualizedScene.min / .max), the gamma list as for rtgpu_tonemap_multi; rgba[npixels] in host memory. */
+int rtgpu_tonemap_pixelmap(rtgpu_ctx *ctx, const void *map, const rtgpu_pixel_layout *layout, int64_t npixels, const float *minmax,
+                           const float *gammas, int32_t ngammas, uint32_t *rgba);
+/* No counterpart in the reference: page-locked host memory for the big host buffers of the two calls above (NULL if it
+ * cannot be had; a caller then falls back to malloc).  Allocating and freeing it is slow: keep it from frame to frame. */
+void *rtgpu_pinned_alloc(size_t bytes);
+void rtgpu_pinned_free(void *p);
 
 /* Introspection used by the parity tests: grid lists (cell_start: ncells+1, refs: nrefs, ascending
  * triangle index inside a cell as src/voxelize.c:252-283 inserts them) and the per-triangle

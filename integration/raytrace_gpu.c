@@ -17,6 +17,8 @@
  */
 #include <errno.h>
 #include <float.h>
+#include <stddef.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,6 +36,7 @@ static rtgpu_ctx *g_ctx; /* one context per process and GPU, created at the firs
  * libraries, so this one restores the value main() expects. */
 __attribute__((constructor)) static void clear_load_time_errno(void) { errno = 0; }
 
+static void release_at_exit(void);
 static rtgpu_ctx *context(void) {
   if (!g_ctx) {
     const char *dev = getenv("RTGPU_DEVICE");
@@ -43,6 +46,7 @@ static rtgpu_ctx *context(void) {
       errno = rc <= E_INVALID_PARAM_VALUE ? rc : E_IO;
       return NULL;
     }
+    atexit(release_at_exit);
   }
   return g_ctx;
 }
@@ -56,39 +60,74 @@ static int gpu_failed(rtgpu_ctx *ctx, int rc) {
 }
 
 
-/* The frame's big host buffers (colours, ids, the pixel map) are kept from call to call: fresh pages for 330 MB per 4K
- * frame cost more than the GPU frame itself.  grab() hands out the cached block if it is large enough (taking it out of
- * the cache), keep() puts a block back in place of a smaller or absent one. */
-struct held { void *p; size_t bytes; };
-static struct held held_rgb, held_ids, held_map;
-static void *grab(struct held *h, size_t bytes, int zero) {
-  void *p;
-  if (h->p && h->bytes >= bytes) { p = h->p; h->p = NULL; h->bytes = 0; if (zero) memset(p, 0, bytes); return p; }
-  return zero ? calloc(1, bytes ? bytes : 1) : malloc(bytes ? bytes : 1);
+/* The pixel map (24 bytes per pixel: 199 MB for a 4K frame) is page-locked memory, which the GPU fills at the full rate of
+ * the host link, and is kept from call to call: pinning fresh pages for every frame costs more than the frame itself.  A
+ * block starts with a header that says how it was obtained; the map the caller sees lies 64 bytes behind it. */
+struct map_hdr { uint64_t magic; size_t bytes; int pinned; };
+#define MAP_MAGIC 0x52544d4150484452ull
+#define MAP_HDR 64
+static struct map_hdr *held_map; /* the block of the last destroyed frame, for the next one */
+static void block_free(struct map_hdr *h) {
+  if (!h) return;
+  if (h->pinned) rtgpu_pinned_free(h); else free(h);
 }
-static void keep(struct held *h, void *p, size_t bytes) {
-  if (!p) return;
-  if (!h->p || h->bytes < bytes) { free(h->p); h->p = p; h->bytes = bytes; } else free(p);
+static void *map_grab(size_t bytes) {
+  struct map_hdr *h = held_map;
+  held_map = NULL;
+  if (h && h->bytes < bytes) { block_free(h); h = NULL; }
+  if (!h) {
+    int pinned = 1;
+    h = rtgpu_pinned_alloc(bytes + MAP_HDR);
+    if (!h) { pinned = 0; h = malloc(bytes + MAP_HDR); }
+    if (!h) return NULL;
+    h->magic = MAP_MAGIC; h->bytes = bytes; h->pinned = pinned;
+  }
+  return (char *)h + MAP_HDR;
+}
+static void map_release(void *map) {
+  struct map_hdr *h;
+  if (!map) return;
+  h = (struct map_hdr *)((char *)map - MAP_HDR);
+  if (h->magic != MAP_MAGIC) return; /* not one of ours */
+  if (!held_map || held_map->bytes < h->bytes) { block_free(held_map); held_map = h; } else block_free(h);
+}
+/* At the end of the program: the kept block and the GPU context.  Registered with atexit when the context is created,
+ * i.e. after the GPU runtime has registered its own exit handlers, so that it runs before them. */
+static void release_at_exit(void) {
+  block_free(held_map); held_map = NULL;
+  if (g_ctx) { rtgpu_destroy(g_ctx); g_ctx = NULL; }
+}
+
+/* RT_VisualizedScenePixel as the GPU library is told about it (src/raytrace.h:23-27) */
+static rtgpu_pixel_layout pixel_layout(const RT_Scene *scene) {
+  rtgpu_pixel_layout l;
+  l.stride = (int64_t)sizeof(RT_VisualizedScenePixel);
+  l.color_offset = (int64_t)offsetof(RT_VisualizedScenePixel, c);
+  l.tri_offset = (int64_t)offsetof(RT_VisualizedScenePixel, t);
+  l.tri_base = scene ? (uint64_t)(uintptr_t)scene->t : 0;
+  l.tri_stride = (int64_t)sizeof(RT_Triangle);
+  return l;
 }
 
 RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera) {
   const size_t np = (size_t)camera->sw * (size_t)camera->sh;
   const int32_t nt = scene->nt, ns = scene->ns, nl = scene->nl, npl = scene->npl;
   RT_VisualizedScene *res = calloc(1, sizeof *res);
-  float *verts = NULL, *rgb = NULL, mm[6];
-  int32_t *sid = NULL, *ids = NULL;
+  float *verts = NULL, mm[6];
+  int32_t *sid = NULL;
   rtgpu_surface *surf = NULL;
   rtgpu_light *lgt = NULL;
   rtgpu_planar_light *pl = NULL;
   rtgpu_scene_desc d;
   rtgpu_camera cam;
   rtgpu_grid_info gi;
+  rtgpu_pixel_layout lay;
   rtgpu_ctx *ctx;
   int32_t i;
   int k, ok = 0, saved;
-  size_t p;
 
-  if (!res || !(res->map = grab(&held_map, (np ? np : 1) * sizeof *res->map, np == 0))) { errno = E_MEMORY; goto out; }
+  if (!res || !(res->map = map_grab((np ? np : 1) * sizeof *res->map))) { errno = E_MEMORY; goto out; }
+  if (np == 0) memset(res->map, 0, sizeof *res->map);
   res->width = camera->sw;
   res->height = camera->sh;
   res->gamma = scene->cfg.gamma > 0.0f ? scene->cfg.gamma : 2.5f; /* src/raytrace.c:333-337 */
@@ -102,9 +141,7 @@ RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera
   surf = calloc((size_t)ns + 1, sizeof *surf);
   lgt = calloc((size_t)nl + 1, sizeof *lgt);
   pl = calloc((size_t)npl + 1, sizeof *pl);
-  rgb = grab(&held_rgb, sizeof(float) * 3 * (np ? np : 1), 0);
-  ids = grab(&held_ids, sizeof(int32_t) * (np ? np : 1), 0);
-  if (!verts || !sid || !surf || !lgt || !pl || !rgb || !ids) { errno = E_MEMORY; goto out; }
+  if (!verts || !sid || !surf || !lgt || !pl) { errno = E_MEMORY; goto out; }
   memset(&d, 0, sizeof d);
   for (i = 0; i < nt; i++) {
     const RT_Triangle *t = &scene->t[i];
@@ -134,40 +171,37 @@ RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera
   d.gamma = scene->cfg.gamma; d.distmod = scene->cfg.distmod; d.vmode = (int32_t)scene->cfg.vmode;
   for (k = 0; k < 3; k++) { cam.ob[k] = camera->ob[k]; cam.ul[k] = camera->ul[k]; cam.bl[k] = camera->bl[k]; cam.ur[k] = camera->ur[k]; }
   cam.sw = camera->sw; cam.sh = camera->sh;
+  lay = pixel_layout(scene);
 
-  /* the GPU does what src/raytrace.c:346-404 does.  The GPU runtime may leave stray errno values (ENOENT, EAGAIN ...)
-   * on paths that worked, and the caller reads errno (src/main.c:190): keep the value the host code had. */
+  /* the GPU does what src/raytrace.c:346-404 does and writes the pixel map itself (an upload of the scene the context
+   * already holds costs a comparison).  The GPU runtime may leave stray errno values (ENOENT, EAGAIN ...) on paths that
+   * worked, and the caller reads errno (src/main.c:190): keep the value the host code had. */
   saved = errno;
   if (!(ctx = context())) goto out;
   if (gpu_failed(ctx, rtgpu_scene_upload(ctx, &d))) goto out;
   if (gpu_failed(ctx, rtgpu_frame_begin(ctx, &cam))) goto out;
-  if (gpu_failed(ctx, rtgpu_render_host(ctx, rgb, ids, mm))) goto out;
+  if (np > 0 && gpu_failed(ctx, rtgpu_render_pixelmap(ctx, res->map, &lay, mm))) goto out;
   if (gpu_failed(ctx, rtgpu_grid_info_get(ctx, &gi))) goto out;
   errno = saved;
 
-  /* results into the reference's structures */
+  /* results into the reference's structures.  (The reference leaves the pixels whose ray never enters the grid, and every
+   * pixel's fourth colour lane, as malloc handed them out, src/raytrace.c:323,381-382; here they are defined: 0.) */
   res->total_flux = gi.total_flux;
   for (k = 0; k < 3; k++) {
-    res->min.c[k] = mm[k]; res->max.c[k] = mm[3 + k];
+    res->min.c[k] = np > 0 ? mm[k] : FLT_MAX; res->max.c[k] = np > 0 ? mm[3 + k] : FLT_MIN;
     scene->dmin[k] = gi.dmin[k]; scene->dmax[k] = gi.dmax[k]; /* the reference grows the domain in place (src/raytrace.c:350-353, src/voxelize.c:140-141) */
   }
   res->min.c[3] = FLT_MAX; res->max.c[3] = FLT_MIN; /* src/raytrace.c:317-320: the alpha lane is never updated */
-  for (p = 0; p < np; p++) {
-    res->map[p].c.c[0] = rgb[3 * p]; res->map[p].c.c[1] = rgb[3 * p + 1]; res->map[p].c.c[2] = rgb[3 * p + 2];
-    res->map[p].c.c[3] = 0.0f; /* (the reference's map comes from calloc) */
-    res->map[p].t = ids[p] >= 0 ? &scene->t[ids[p]] : NULL;
-  }
   ok = 1;
 out:
   free(verts); free(sid); free(surf); free(lgt); free(pl);
-  keep(&held_rgb, rgb, sizeof(float) * 3 * (np ? np : 1)); keep(&held_ids, ids, sizeof(int32_t) * (np ? np : 1));
   if (!ok) rtVisualizedSceneDestroy(&res);
   return res;
 }
 
 void rtVisualizedSceneDestroy(RT_VisualizedScene **self) {
   if (self && *self) {
-    keep(&held_map, (*self)->map, (size_t)((*self)->width > 0 ? (*self)->width : 0) * (size_t)((*self)->height > 0 ? (*self)->height : 0) * sizeof *(*self)->map);
+    map_release((*self)->map);
     free(*self); *self = NULL;
   }
 }
@@ -175,25 +209,19 @@ void rtVisualizedSceneDestroy(RT_VisualizedScene **self) {
 RT_Bitmap *rtVisualizedSceneToBitmap(RT_VisualizedScene *s, int flags, void *param1) {
   const size_t np = (size_t)s->width * (size_t)s->height;
   RT_Bitmap *bmp = rtBitmapCreate(s->width, s->height, 0);
+  const rtgpu_pixel_layout lay = pixel_layout(NULL);
+  const float *gammas = param1 ? (const float *)param1 : &s->gamma; /* src/raytrace.c:439-440 */
+  int32_t ng = 0;
   rtgpu_ctx *ctx;
-  float *rgb, mm[6], gamma = s->gamma;
-  size_t p;
+  float mm[6];
   int k, saved;
   if (!bmp) return NULL;
   if (!(flags & F_HDR)) return bmp; /* src/raytrace.c:437: nothing is drawn without F_HDR */
-  if (param1) { /* zero-terminated gamma list (src/raytrace.c:439-447); the GPU tone map takes one gamma */
-    const float *g = param1;
-    if (!(g[0] > 0.0f) || g[1] > 0.0f) { errno = E_INVALID_PARAM_VALUE; rtBitmapDestroy(&bmp); return NULL; }
-    gamma = g[0];
-  }
+  if (param1) { while (gammas[ng] > 0.0f) ng++; } else ng = s->gamma > 0.0f ? 1 : 0; /* the zero-terminated list, src/raytrace.c:445-447 */
   saved = errno;
   if (!(ctx = context())) { rtBitmapDestroy(&bmp); return NULL; }
-  rgb = grab(&held_rgb, sizeof(float) * 3 * (np ? np : 1), 0);
-  if (!rgb) { errno = E_MEMORY; rtBitmapDestroy(&bmp); return NULL; }
-  for (p = 0; p < np; p++) for (k = 0; k < 3; k++) rgb[3 * p + k] = s->map[p].c.c[k];
   for (k = 0; k < 3; k++) { mm[k] = s->min.c[k]; mm[3 + k] = s->max.c[k]; }
-  if (gpu_failed(ctx, rtgpu_tonemap_host(ctx, rgb, (int64_t)np, mm, gamma, bmp->pixels))) rtBitmapDestroy(&bmp);
+  if (gpu_failed(ctx, rtgpu_tonemap_pixelmap(ctx, s->map, &lay, (int64_t)np, mm, gammas, ng, bmp->pixels))) rtBitmapDestroy(&bmp);
   else errno = saved;
-  keep(&held_rgb, rgb, sizeof(float) * 3 * (np ? np : 1));
   return bmp;
 }

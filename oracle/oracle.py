@@ -58,6 +58,7 @@ def lib():
         L.ora_triangles.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ora_tonemap.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.ora_tonemap_multi.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ora_bmp24.restype = C.c_int64
         L.ora_bmp24.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ora_rand_fill.argtypes = [C.c_void_p, C.c_int64]
@@ -133,10 +134,16 @@ class OracleScene:
 
 
 def tonemap(rgb, minmax, gamma):
+    """gamma: one gamma, or a list of them (the reference's zero-terminated list without its terminator,
+    raytrace.c:439-447: the channels are averaged over the list)."""
     h, w, _ = rgb.shape
     out = np.zeros((h, w), np.uint32)
     rgb = np.ascontiguousarray(rgb, np.float32); mm = np.ascontiguousarray(minmax, np.float32)
-    lib().ora_tonemap(w, h, _p(rgb), _p(mm), C.c_float(gamma), _p(out))
+    if isinstance(gamma, (list, tuple, np.ndarray)):
+        g = np.ascontiguousarray(gamma, np.float32)
+        lib().ora_tonemap_multi(w, h, _p(rgb), _p(mm), _p(g) if g.size else None, int(g.size), _p(out))
+    else:
+        lib().ora_tonemap(w, h, _p(rgb), _p(mm), C.c_float(gamma), _p(out))
     return out
 
 
@@ -166,8 +173,9 @@ def have_reference():
     return os.path.exists(REF_BIN)
 
 
-def run_reference(prefix, width=None, height=None, cwd=None, want_bmp=False, **over):
-    """Runs the compiled reference; returns dict(rgb, ids, minmax, gamma, seconds, bmp bytes|None)."""
+def run_reference(prefix, width=None, height=None, cwd=None, want_bmp=False, gammas=None, **over):
+    """Runs the compiled reference; returns dict(rgb, ids, minmax, gamma, seconds, bmp bytes|None).
+    gammas: a list handed to the reference's rtVisualizedSceneToBitmap as its zero-terminated param1."""
     p = scene_paths(prefix, **over)
     with tempfile.TemporaryDirectory() as td:
         dump = os.path.join(td, "d.bin"); bmp = os.path.join(td, "o.bmp")
@@ -177,6 +185,8 @@ def run_reference(prefix, width=None, height=None, cwd=None, want_bmp=False, **o
             cmd += ["-W", str(width), "-H", str(height)]
         if want_bmp:
             cmd += ["-o", bmp]
+        if gammas is not None:
+            cmd += ["-G", ",".join(repr(float(g)) for g in gammas) + ","]
         cmd = [os.path.abspath(c) if os.path.exists(c) else c for c in cmd]
         out = subprocess.run(cmd, cwd=cwd, check=True, capture_output=True, text=True).stdout
         meta = json.loads(out.strip().splitlines()[-1])

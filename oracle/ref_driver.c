@@ -11,7 +11,9 @@
  * id = index of the primary-hit triangle or -1.
  *
  * usage: ref_dump -s PREFIX [-g brs] [-l lgt] [-L pnr] [-a atr] [-c cam] [-C cfg]
- *                 [-W width -H height] [-d dump.bin] [-o out.bmp]
+ *                 [-W width -H height] [-d dump.bin] [-o out.bmp] [-G g1,g2,...]
+ * -G: a comma-separated gamma list, passed zero-terminated to the reference's rtVisualizedSceneToBitmap as its
+ * param1 (/root/reference/src/raytrace.c:439-447); "-G ," is the empty list.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,8 +34,9 @@ static char *cat(const char *a, const char *b) {
 
 int main(int argc, char **argv) {
   const char *g = NULL, *l = NULL, *L = NULL, *a = NULL, *c = NULL, *C = NULL, *s = NULL;
-  const char *dump = NULL, *out = NULL;
-  int W = 0, H = 0, i;
+  const char *dump = NULL, *out = NULL, *glist = NULL;
+  float gammas[65];
+  int W = 0, H = 0, i, ng = 0;
   uint32_t n;
 
   /* Large blocks come from fresh (zeroed) mmaps, so that pixels the reference
@@ -50,6 +53,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(k, "-s")) s = v; else if (!strcmp(k, "-d")) dump = v;
     else if (!strcmp(k, "-o")) out = v; else if (!strcmp(k, "-W")) W = atoi(v);
     else if (!strcmp(k, "-H")) H = atoi(v);
+    else if (!strcmp(k, "-G")) glist = v;
     else { fprintf(stderr, "unknown option %s\n", k); return 2; }
   }
   if (s) {
@@ -114,7 +118,18 @@ int main(int argc, char **argv) {
     fclose(f);
   }
   if (out) {
-    RT_Bitmap *bmp = rtVisualizedSceneToBitmap(vs, F_HDR, NULL);
+    if (glist) {
+      const char *q = glist;
+      while (*q && ng < 64) {
+        char *end;
+        float gv = strtof(q, &end);
+        if (end == q) break;
+        gammas[ng++] = gv;
+        q = *end == ',' ? end + 1 : end;
+      }
+      gammas[ng] = 0.0f;
+    }
+    RT_Bitmap *bmp = rtVisualizedSceneToBitmap(vs, F_HDR, glist ? gammas : NULL);
     rtBitmapSave(bmp, out, 24);
     rtBitmapDestroy(&bmp);
   }

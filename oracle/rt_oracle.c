@@ -817,18 +817,24 @@ static inline uint32_t f2u_x86(float x) { /* float -> uint32_t: 64-bit cvttss2si
   if (!(x > -9223373136366403584.0f && x < 9223372036854775808.0f)) return 0u;
   return (uint32_t)(uint64_t)(int64_t)x;
 }
-void ora_tonemap(int w, int h, const float *rgb, const float *mm, float gamma, uint32_t *rgba) {
-  float delta[3]; size_t p, np = (size_t)w * h; int k;
+/* raytrace.c:439-466: the zero-terminated gamma list (param1) as n gammas; per channel `r += pow(x, gammas[k]) * 255.0f`
+ * (double product, double sum, rounded to float at every +=), then r / (float)n, converted to uint32_t and masked
+ * (bitmap.h:70).  n = 0 (an empty list): 0.0f / 0.0f = NaN, which the conversion turns into 0. */
+void ora_tonemap_multi(int w, int h, const float *rgb, const float *mm, const float *gammas, int n, uint32_t *rgba) {
+  float delta[3]; size_t p, np = (size_t)w * h; int k, q;
   for (k = 0; k < 3; k++) delta[k] = 1.0f / (mm[3 + k] - mm[k]);
   for (p = 0; p < np; p++) {
     uint32_t ch[3];
     for (k = 0; k < 3; k++) {
       float acc = 0.0f;
-      acc += pow((rgb[p * 3 + k] - mm[k]) * delta[k], gamma) * 255.0f;
-      ch[k] = f2u_x86(acc / (float)1);
+      for (q = 0; q < n; q++) acc += pow((rgb[p * 3 + k] - mm[k]) * delta[k], gammas[q]) * 255.0f;
+      ch[k] = f2u_x86(acc / (float)n);
     }
     rgba[p] = ((ch[0] & 0xff) << 24) | ((ch[1] & 0xff) << 16) | ((ch[2] & 0xff) << 8);
   }
+}
+void ora_tonemap(int w, int h, const float *rgb, const float *mm, float gamma, uint32_t *rgba) {
+  ora_tonemap_multi(w, h, rgb, mm, &gamma, 1, rgba); /* raytrace.c:439: the default list is {s->gamma, 0} */
 }
 int64_t ora_bmp24(int w, int h, const uint32_t *rgba, uint8_t *out) {
   uint32_t row = (uint32_t)(4 * ceil(24 * w / 32.0)); /* bitmap.c:307 */

@@ -62,6 +62,8 @@ void ora_vertices(const ora_scene *s, float *out9, int32_t *sid);
 
 /* Tone map (raytrace.c:424-472): rgba packed R<<24|G<<16|B<<8|A per pixel. */
 void ora_tonemap(int w, int h, const float *rgb, const float *minmax, float gamma, uint32_t *rgba);
+/* ... with the zero-terminated gamma list of raytrace.c:439-447 given as n gammas (averaged per channel, raytrace.c:456-466) */
+void ora_tonemap_multi(int w, int h, const float *rgb, const float *minmax, const float *gammas, int n, uint32_t *rgba);
 /* 24-bpp BMP file image (bitmap.c:249-479); returns byte count, writes into out if non-NULL. */
 int64_t ora_bmp24(int w, int h, const uint32_t *rgba, uint8_t *out);
 

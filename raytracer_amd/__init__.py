@@ -7,8 +7,8 @@ Python is plumbing here (ctypes calls, numpy/torch buffers, torch.distributed fo
 exchange); all rendering happens in the HIP kernels.  Importing works without a GPU; creating a
 ``Renderer`` does not: there is no CPU rendering path.
 """
-from .api import (Camera, Counters, csrc_hash, GridInfo, Renderer, RtgpuError, Scene, Timings, build_native, host_lib,
+from .api import (Camera, Counters, csrc_hash, GridInfo, PixelLayout, Renderer, RtgpuError, Scene, Timings, build_native, host_lib,
                   gpu_lib, render_bmp, save_bmp24, scene_paths, TILE, TILE_PIXELS)
 
-__all__ = ["Camera", "Counters", "GridInfo", "Renderer", "RtgpuError", "Scene", "Timings", "build_native",
+__all__ = ["Camera", "Counters", "GridInfo", "PixelLayout", "Renderer", "RtgpuError", "Scene", "Timings", "build_native",
            "host_lib", "gpu_lib", "csrc_hash", "render_bmp", "save_bmp24", "scene_paths", "TILE", "TILE_PIXELS"]

@@ -79,6 +79,12 @@ class Timings(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class PixelLayout(C.Structure):
+    """rtgpu_pixel_layout: a caller's pixel record (the reference's RT_VisualizedScenePixel is (24, 0, 16, &scene->t[0], 232))."""
+    _fields_ = [("stride", C.c_int64), ("color_offset", C.c_int64), ("tri_offset", C.c_int64), ("tri_base", C.c_uint64),
+                ("tri_stride", C.c_int64)]
+
+
 class SceneFlat(C.Structure):
     _fields_ = [("desc", SceneDesc), ("vertices", C.POINTER(C.c_float)), ("sid", C.POINTER(C.c_int32)),
                 ("surfaces", C.POINTER(Surface)), ("lights", C.POINTER(Light)), ("planar", C.POINTER(PlanarLight))]
@@ -143,6 +149,8 @@ def gpu_lib():
         L.rtgpu_hit_counts.argtypes = [vp, vp]
         L.rtgpu_render_shade.argtypes = [vp, vp, i64, i64, vp, vp, vp]
         L.rtgpu_tonemap.argtypes = [vp, vp, i64, vp, C.c_float, vp]
+        L.rtgpu_tonemap_multi.argtypes = [vp, vp, i64, vp, C.POINTER(C.c_float), i32, vp]
+        L.rtgpu_tonemap_multi_host.argtypes = [vp, vp, i64, vp, C.POINTER(C.c_float), i32, vp]
         L.rtgpu_untile.argtypes = [vp, vp, i32, i32, vp]
         L.rtgpu_bmp_row_bytes.argtypes = [i32, i32]
         L.rtgpu_bmp_row_bytes.restype = C.c_int64
@@ -153,6 +161,12 @@ def gpu_lib():
         L.rtgpu_timings_get.argtypes = [vp, C.POINTER(Timings)]
         L.rtgpu_render_host.argtypes = [vp, vp, vp, vp]
         L.rtgpu_tonemap_host.argtypes = [vp, vp, i64, vp, C.c_float, vp]
+        L.rtgpu_render_pixelmap.argtypes = [vp, vp, C.POINTER(PixelLayout), vp]
+        L.rtgpu_tonemap_pixelmap.argtypes = [vp, vp, C.POINTER(PixelLayout), i64, vp, C.POINTER(C.c_float), i32, vp]
+        L.rtgpu_pinned_alloc.restype = vp
+        L.rtgpu_pinned_alloc.argtypes = [C.c_size_t]
+        L.rtgpu_pinned_free.restype = None
+        L.rtgpu_pinned_free.argtypes = [vp]
         L.rtgpu_grid_download.argtypes = [vp, vp, vp]
         L.rtgpu_triangles_download.argtypes = [vp, vp]
         _gpu = L
@@ -367,8 +381,14 @@ class Renderer:
                                              _ptr(rgb), _ptr(ids), _ptr(minmax)), "rtgpu_render_shade")
 
     def tonemap(self, rgb, npixels, minmax, gamma, rgba):
-        self._chk(self._L.rtgpu_tonemap(self._h, _ptr(rgb), int(npixels), _ptr(minmax), C.c_float(gamma), _ptr(rgba)),
-                  "rtgpu_tonemap")
+        """gamma: one gamma, or a list of them (the reference's zero-terminated list without its terminator)."""
+        if isinstance(gamma, (list, tuple, np.ndarray)):
+            g = (C.c_float * max(len(gamma), 1))(*[float(x) for x in gamma])
+            self._chk(self._L.rtgpu_tonemap_multi(self._h, _ptr(rgb), int(npixels), _ptr(minmax), g, len(gamma), _ptr(rgba)),
+                      "rtgpu_tonemap_multi")
+        else:
+            self._chk(self._L.rtgpu_tonemap(self._h, _ptr(rgb), int(npixels), _ptr(minmax), C.c_float(gamma), _ptr(rgba)),
+                      "rtgpu_tonemap")
 
     def untile(self, gathered, world, elem_bytes, image):
         self._chk(self._L.rtgpu_untile(self._h, _ptr(gathered), world, elem_bytes, _ptr(image)), "rtgpu_untile")
@@ -412,13 +432,47 @@ class Renderer:
         self._chk(self._L.rtgpu_render_host(self._h, _ptr(rgb), _ptr(ids), _ptr(mm)), "rtgpu_render_host")
         return dict(rgb=rgb, ids=ids, minmax=mm)
 
+    def render_pixelmap(self, layout, pinned=True):
+        """Single-GPU frame into the caller's pixel records (rtgpu_render_pixelmap): returns (bytes [h*w, stride] u8, minmax)."""
+        w, h = self.camera.sw, self.camera.sh
+        n = w * h * int(layout.stride)
+        mm = np.zeros(6, np.float32)
+        block = self._L.rtgpu_pinned_alloc(n) if pinned else None
+        if pinned and not block:
+            raise MemoryError("rtgpu_pinned_alloc")
+        try:
+            buf = (C.c_ubyte * n).from_address(block) if pinned else (C.c_ubyte * n)()
+            self._chk(self._L.rtgpu_render_pixelmap(self._h, C.cast(buf, C.c_void_p), C.byref(layout), _ptr(mm)), "rtgpu_render_pixelmap")
+            out = np.frombuffer(buf, np.uint8).reshape(h * w, int(layout.stride)).copy()
+        finally:
+            if pinned:
+                self._L.rtgpu_pinned_free(block)
+        return out, mm
+
+    def tonemap_pixelmap(self, records, layout, minmax, gamma):
+        """rtgpu_tonemap_pixelmap on records [n, stride] u8; gamma: one gamma or a list."""
+        records = np.ascontiguousarray(records, np.uint8)
+        n = records.shape[0]
+        gl = list(gamma) if isinstance(gamma, (list, tuple, np.ndarray)) else [gamma]
+        g = (C.c_float * max(len(gl), 1))(*[float(x) for x in gl])
+        mm = np.ascontiguousarray(minmax, np.float32)
+        out = np.zeros(n, np.uint32)
+        self._chk(self._L.rtgpu_tonemap_pixelmap(self._h, _ptr(records), C.byref(layout), n, _ptr(mm), g, len(gl), _ptr(out)),
+                  "rtgpu_tonemap_pixelmap")
+        return out
+
     def tonemap_host(self, rgb, minmax, gamma):
         h, w, _ = rgb.shape
         rgb = np.ascontiguousarray(rgb, np.float32)
         mm = np.ascontiguousarray(minmax, np.float32)
         out = np.zeros((h, w), np.uint32)
-        self._chk(self._L.rtgpu_tonemap_host(self._h, _ptr(rgb), w * h, _ptr(mm), C.c_float(gamma), _ptr(out)),
-                  "rtgpu_tonemap_host")
+        if isinstance(gamma, (list, tuple, np.ndarray)):
+            g = (C.c_float * max(len(gamma), 1))(*[float(x) for x in gamma])
+            self._chk(self._L.rtgpu_tonemap_multi_host(self._h, _ptr(rgb), w * h, _ptr(mm), g, len(gamma), _ptr(out)),
+                      "rtgpu_tonemap_multi_host")
+        else:
+            self._chk(self._L.rtgpu_tonemap_host(self._h, _ptr(rgb), w * h, _ptr(mm), C.c_float(gamma), _ptr(out)),
+                      "rtgpu_tonemap_host")
         return out
 
     def grid(self):

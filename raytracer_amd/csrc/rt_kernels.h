@@ -2544,10 +2544,12 @@ __global__ void k_fold_stats(const Ctl *__restrict__ ctl, unsigned long long *__
 // binary32 first, then, for the values within 2e-6 of a rounding boundary, in double, within 1e-14 of the true value:
 // if every value within 1e-12 of it gives the same byte, so does any correctly working pow, and the call is
 // skipped; the few values next to a rounding boundary take the pow path like all others.
-__global__ void __launch_bounds__(256) k_tonemap(const float *__restrict__ rgb, long long n, const float *__restrict__ minmax,
+// stride: floats from one pixel's colour to the next (3 for a packed colour buffer; a caller's pixel records may be wider).
+__global__ void __launch_bounds__(256) k_tonemap(const float *__restrict__ rgb_, long long stride, long long n, const float *__restrict__ minmax,
                                                  float gamma, uint32_t *__restrict__ rgba) {
   long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
+  const float *__restrict__ rgb = rgb_ + (stride - 3) * p;  // (so that rgb[3 p + k] below is channel k of pixel p)
   const float twice = gamma + gamma;
   const int halves = (twice >= 1.0f && twice <= 8.0f && twice == (float)(int)twice) ? (int)twice : 0;  // gamma = halves / 2
   uint32_t ch[3];
@@ -2588,6 +2590,25 @@ __global__ void __launch_bounds__(256) k_tonemap(const float *__restrict__ rgb, 
   rgba[p] = (ch[0] << 24) | (ch[1] << 16) | (ch[2] << 8);
 }
 
+// The tone map with a list of gammas (raytrace.c:439-466): per channel `r += pow(x, gamma_k) * 255.0f` for every gamma of
+// the list (product and sum in double, rounded to float at every +=), then r / (float)ng, converted like a single gamma's
+// value.  An empty list gives 0.0f / 0.0f = NaN, which the conversion turns into 0.
+__global__ void __launch_bounds__(256) k_tonemap_multi(const float *__restrict__ rgb, long long stride, long long n, const float *__restrict__ minmax,
+                                                       const float *__restrict__ gammas, int ng, uint32_t *__restrict__ rgba) {
+  long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t ch[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float delta = 1.0f / (minmax[3 + k] - minmax[k]);
+    const float x = (rgb[stride * p + k] - minmax[k]) * delta;
+    float acc = 0.0f;
+    for (int q = 0; q < ng; q++) acc = (float)((double)acc + pow((double)x, (double)gammas[q]) * 255.0);
+    ch[k] = f2u_x86(acc / (float)ng) & 0xffu;
+  }
+  rgba[p] = (ch[0] << 24) | (ch[1] << 16) | (ch[2] << 8);
+}
+
 // BMP pixel rows on the device (bitmap.c:453-469): bottom-up, B G R [0] per pixel, every row padded with zeros to a
 // multiple of four bytes.  One thread per 32-bit word of the output, so the stores coalesce; words = row_bytes / 4.
 __global__ void __launch_bounds__(256) k_bmp_rows(const uint32_t *__restrict__ image, int w, int h, int bytes_pp, int words,
@@ -2603,6 +2624,32 @@ __global__ void __launch_bounds__(256) k_bmp_rows(const uint32_t *__restrict__ i
     if (x < w && ch < 3) out |= ((src[x] >> (8 + 8 * ch)) & 0xffu) << (8 * b);  // pixel = R<<24 | G<<16 | B<<8 (bitmap.h:70)
   }
   rows[q] = out;
+}
+
+// The frame of one rank in the caller's own pixel records (the reference's RT_VisualizedScenePixel, raytrace.h:23-27: a
+// colour of four floats and a pointer to the primary-hit triangle), row-major, from the tile-major buffers of the pixel
+// loop.  The pointer is an address of the CALLER's address space, tri_base + id x tri_stride, or null without a hit: it is
+// worked out here as a number and never followed.  The colour's fourth lane, and every byte of a record that neither
+// member covers, is 0.  tri_offset < 0: records without a pointer.
+struct PixelLayoutD { long long stride, color_offset, tri_offset; unsigned long long tri_base; long long tri_stride; };
+__global__ void __launch_bounds__(256) k_pixelmap(const float *__restrict__ rgb_t, const int32_t *__restrict__ ids_t, int w, int h, int tiles_x,
+                                                  PixelLayoutD lay, unsigned char *__restrict__ map) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long long)w * h) return;
+  const int x = (int)(p % w), y = (int)(p / w);
+  const long long s = ((long long)(y >> 3) * tiles_x + (x >> 3)) * kTilePixels + (y & 7) * kTile + (x & 7);
+  // the record word by word: colour, pointer halves, and 0 for what no member covers
+  uint32_t *rec = reinterpret_cast<uint32_t *>(map + p * lay.stride);
+  const int32_t id = lay.tri_offset >= 0 ? ids_t[s] : -1;
+  const unsigned long long ptr = id >= 0 ? lay.tri_base + (unsigned long long)id * (unsigned long long)lay.tri_stride : 0ull;
+  const int cw = (int)(lay.color_offset >> 2), tw = lay.tri_offset >= 0 ? (int)(lay.tri_offset >> 2) : -2, nw = (int)(lay.stride >> 2);
+  for (int q = 0; q < nw; q++) {
+    uint32_t v = 0u;
+    if (q >= cw && q < cw + 3) v = __float_as_uint(rgb_t[3 * s + (q - cw)]);
+    else if (q == tw) v = (uint32_t)ptr;
+    else if (q == tw + 1) v = (uint32_t)(ptr >> 32);
+    rec[q] = v;
+  }
 }
 
 // Tile-major blocks of all ranks (rank-major, then local tile, then 64 slots) -> row-major image.

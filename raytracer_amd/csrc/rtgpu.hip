@@ -135,6 +135,15 @@ struct rtgpu_ctx {
   int32_t *h_ids_t = nullptr, *h_ids = nullptr;
   uint32_t *h_rgba = nullptr;
   size_t h_cap_tiles = 0, h_cap_px = 0, h_cap_tone = 0;
+  float *d_gammas = nullptr;  // the gamma list of rtgpu_tonemap_multi
+  size_t cap_gammas = 0;
+  unsigned char *h_map = nullptr;  // device copy of a caller's pixel records (rtgpu_render_pixelmap, rtgpu_tonemap_pixelmap)
+  size_t h_cap_map = 0;
+  // host copy of the uploaded scene's arrays: an upload of the same scene again is recognised and skipped
+  std::vector<float> up_verts;
+  std::vector<int32_t> up_sid;
+  std::vector<rtgpu_planar_light> up_planar;
+  size_t cap_nt = 0, cap_ns = 0, cap_nl = 0, cap_npl = 0;  // what the scene's device arrays were allocated for
   // timing
   std::vector<TimedSpan> spans;
   rtgpu_timings timings = {};
@@ -448,7 +457,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_nbatch); dev_free(&c->d_hdr_start); dev_free(&c->d_occ); dev_free(&c->d_hdrs); dev_free(&c->d_bucket);
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
-  dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba);
+  dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba); dev_free(&c->d_gammas); dev_free(&c->h_map);
   dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_order); dev_free(&c->d_split_keys); dev_free(&c->d_split_masks); dev_free(&c->d_split_done_n); dev_free(&c->d_split_done_s); dev_free(&c->d_ctl); dev_free(&c->d_totals);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -496,6 +505,28 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
       (s->nl > 0 && !s->lights) || (s->npl > 0 && !s->planar))
     return fail(c, RTGPU_E_INVALID_PARAM, "scene description incomplete");
   HIPCHK(c, hipSetDevice(c->device));
+  // The scene that is already there, again (a host that calls the reference's frame function once per frame hands the
+  // same scene over every time): nothing to do, and what is known about it (grid sizes, queue sizes) stays known.  The
+  // same arrays with another domain or configuration (the reference's frame function grows RT_Scene.dmin / dmax at every
+  // call, src/raytrace.c:350-353, src/voxelize.c:140-141, and its drop-in hands that back): only the numbers
+  // rtgpu_frame_begin works from change, and the size of the next grid has to be read back once.
+  if (c->have_scene && c->nt == s->nt && c->ns == s->ns && c->nl == s->nl && c->npl == s->npl && c->texture_present == s->texture_present &&
+      !memcmp(c->up_verts.data(), s->vertices, sizeof(float) * 9 * (size_t)s->nt) && !memcmp(c->up_sid.data(), s->sid, sizeof(int32_t) * (size_t)s->nt) &&
+      !memcmp(c->surfaces.data(), s->surfaces, sizeof(rtgpu_surface) * (size_t)s->ns) &&
+      (s->nl == 0 || !memcmp(c->lights.data(), s->lights, sizeof(rtgpu_light) * (size_t)s->nl)) &&
+      (s->npl == 0 || !memcmp(c->up_planar.data(), s->planar, sizeof(rtgpu_planar_light) * (size_t)s->npl))) {
+    const bool same_numbers = !memcmp(c->dmin0, s->dmin, sizeof c->dmin0) && !memcmp(c->dmax0, s->dmax, sizeof c->dmax0) &&
+                              !memcmp(&c->gamma, &s->gamma, sizeof(float)) && !memcmp(&c->distmod, &s->distmod, sizeof(float)) &&
+                              c->vmode == s->vmode && !memcmp(c->vcoeff, s->vcoeff, sizeof c->vcoeff);
+    if (!same_numbers) {
+      memcpy(c->dmin0, s->dmin, sizeof c->dmin0); memcpy(c->dmax0, s->dmax, sizeof c->dmax0);
+      c->gamma = s->gamma; c->distmod = s->distmod; c->vmode = s->vmode;
+      memcpy(c->vcoeff, s->vcoeff, sizeof c->vcoeff);
+      c->known_nrefs = -1;
+      c->have_frame = false;
+    }
+    return RTGPU_OK;
+  }
   for (int t = 0; t < s->nt; t++)
     if (s->sid[t] < 0 || s->sid[t] >= s->ns) return fail(c, RTGPU_E_NOT_ENOUGH_SURFACES, "surface id out of range");
   c->have_scene = c->have_frame = false;
@@ -503,6 +534,9 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   c->nt = s->nt; c->ns = s->ns; c->nl = s->nl; c->npl = s->npl;
   c->lights.assign(s->lights, s->lights + s->nl);
   c->surfaces.assign(s->surfaces, s->surfaces + s->ns);
+  c->up_verts.assign(s->vertices, s->vertices + 9 * (size_t)s->nt);
+  c->up_sid.assign(s->sid, s->sid + s->nt);
+  c->up_planar.assign(s->planar, s->planar + s->npl);
   memcpy(c->dmin0, s->dmin, sizeof c->dmin0); memcpy(c->dmax0, s->dmax, sizeof c->dmax0);
   c->gamma = s->gamma; c->distmod = s->distmod; c->vmode = s->vmode;
   memcpy(c->vcoeff, s->vcoeff, sizeof c->vcoeff);
@@ -552,13 +586,24 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   for (int L = 0; L < kMaxLevels; L++) c->ratio[L] = L == 0 ? 1.0 : 0.0;
   worst_case_factors(c);
   int rc;
-  if ((rc = dev_alloc(c, &c->d_verts, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->d_geom, (size_t)s->nt * 9)) ||
-      (rc = dev_alloc(c, &c->d_aux, (size_t)s->nt * 4)) || (rc = dev_alloc(c, &c->d_filt, (size_t)s->nt * kRecFloats)) || (rc = dev_alloc(c, &c->d_sid, (size_t)s->nt)) ||
-      (rc = dev_alloc(c, &c->d_box, (size_t)s->nt * 6 + ((size_t)s->nt + 63) / 64 * 6)) || (rc = dev_alloc(c, &c->d_surf, (size_t)s->ns)) ||
-      (rc = dev_alloc(c, &c->d_lights, (size_t)s->nl)) || (rc = dev_alloc(c, &c->d_planar, (size_t)s->npl)) ||
-      (rc = dev_alloc(c, &c->alt.d_geom, (size_t)s->nt * 9)) || (rc = dev_alloc(c, &c->alt.d_aux, (size_t)s->nt * 4)))
-    return rc;
-  c->released_valid[0] = c->released_valid[1] = false;  // (hipFree in dev_alloc waited for everything in flight)
+  // the kernels of earlier frames may still read what is replaced below
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->build_stream));
+  c->released_valid[0] = c->released_valid[1] = false;
+  // the scene's device arrays are kept from upload to upload and only grow
+  const size_t nt = (size_t)s->nt;
+  if (nt > c->cap_nt) {
+    c->cap_nt = 0;
+    if ((rc = dev_alloc(c, &c->d_verts, nt * 9)) || (rc = dev_alloc(c, &c->d_geom, nt * 9)) ||
+        (rc = dev_alloc(c, &c->d_aux, nt * 4)) || (rc = dev_alloc(c, &c->d_filt, nt * kRecFloats)) || (rc = dev_alloc(c, &c->d_sid, nt)) ||
+        (rc = dev_alloc(c, &c->d_box, nt * 6 + (nt + 63) / 64 * 6)) ||
+        (rc = dev_alloc(c, &c->alt.d_geom, nt * 9)) || (rc = dev_alloc(c, &c->alt.d_aux, nt * 4)))
+      return rc;
+    c->cap_nt = nt;
+  }
+  if ((size_t)s->ns > c->cap_ns) { c->cap_ns = 0; if ((rc = dev_alloc(c, &c->d_surf, (size_t)s->ns))) return rc; c->cap_ns = (size_t)s->ns; }
+  if ((size_t)s->nl > c->cap_nl || !c->d_lights) { c->cap_nl = 0; if ((rc = dev_alloc(c, &c->d_lights, (size_t)s->nl))) return rc; c->cap_nl = (size_t)s->nl; }
+  if ((size_t)s->npl > c->cap_npl || !c->d_planar) { c->cap_npl = 0; if ((rc = dev_alloc(c, &c->d_planar, (size_t)s->npl))) return rc; c->cap_npl = (size_t)s->npl; }
   static_assert(sizeof(rtgpu_surface) == sizeof(SurfaceD) && sizeof(rtgpu_light) == sizeof(LightD) &&
                     sizeof(rtgpu_planar_light) == sizeof(PlanarD) && sizeof(rtgpu_camera) == sizeof(CameraD),
                 "ABI structs and device structs share one layout");
@@ -1099,13 +1144,40 @@ int rtgpu_render_shade(rtgpu_ctx *c, const int32_t *d_all_counts, int64_t per_ra
   return RTGPU_OK;
 }
 
+namespace {
+// The tone map of n pixels whose colours lie `stride` floats apart, for a list of ng gammas (host memory).
+int tonemap_strided(rtgpu_ctx *c, const float *d_rgb, int64_t stride, int64_t n, const float *d_minmax, const float *gammas, int32_t ng,
+                    uint32_t *d_rgba) {
+  if (n == 0) return RTGPU_OK;
+  const dim3 blocks((unsigned)((n + 255) / 256));
+  if (ng == 1) {  // one gamma: the kernel with the short forms of the power
+    KLAUNCH(c, k_tonemap, blocks, dim3(256), c->stream, d_rgb, (long long)stride, (long long)n, d_minmax, gammas[0], d_rgba);
+  } else {
+    if ((size_t)ng > c->cap_gammas) {
+      int rc = dev_alloc(c, &c->d_gammas, (size_t)ng + 16);
+      if (rc) { c->cap_gammas = 0; return rc; }
+      c->cap_gammas = (size_t)ng + 16;
+    }
+    // (from pageable memory the copy has left the caller's array when the call returns)
+    if (ng > 0) HIPCHK(c, hipMemcpyAsync(c->d_gammas, gammas, sizeof(float) * (size_t)ng, hipMemcpyHostToDevice, c->stream));
+    KLAUNCH(c, k_tonemap_multi, blocks, dim3(256), c->stream, d_rgb, (long long)stride, (long long)n, d_minmax, (const float *)c->d_gammas, (int)ng, d_rgba);
+  }
+  HIPCHK(c, hipGetLastError());
+  return RTGPU_OK;
+}
+}  // namespace
+
 int rtgpu_tonemap(rtgpu_ctx *c, const float *d_rgb, int64_t n, const float *d_minmax, float gamma, uint32_t *d_rgba) {
   if (!c || !d_rgb || !d_minmax || !d_rgba || n < 0) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));
-  if (n == 0) return RTGPU_OK;
-  KLAUNCH(c, k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), c->stream, d_rgb, (long long)n, d_minmax, gamma, d_rgba);
-  HIPCHK(c, hipGetLastError());
-  return RTGPU_OK;
+  return tonemap_strided(c, d_rgb, 3, n, d_minmax, &gamma, 1, d_rgba);
+}
+
+int rtgpu_tonemap_multi(rtgpu_ctx *c, const float *d_rgb, int64_t n, const float *d_minmax, const float *gammas, int32_t ngammas,
+                        uint32_t *d_rgba) {
+  if (!c || !d_rgb || !d_minmax || !d_rgba || n < 0 || ngammas < 0 || (ngammas > 0 && !gammas)) return RTGPU_E_INVALID_PARAM;
+  HIPCHK(c, hipSetDevice(c->device));
+  return tonemap_strided(c, d_rgb, 3, n, d_minmax, gammas, ngammas, d_rgba);
 }
 
 int rtgpu_untile(rtgpu_ctx *c, const void *d_gathered, int world, int elem_bytes, void *d_image) {
@@ -1284,8 +1356,87 @@ int rtgpu_render_host(rtgpu_ctx *c, float *rgb, int32_t *ids, float *minmax) {
   return RTGPU_OK;
 }
 
+void *rtgpu_pinned_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void rtgpu_pinned_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+namespace {
+int check_layout(rtgpu_ctx *c, const rtgpu_pixel_layout *lay) {
+  if (!lay || lay->stride < 16 || lay->stride % 4 || lay->color_offset < 0 || lay->color_offset % 4 || lay->color_offset + 16 > lay->stride ||
+      (lay->tri_offset >= 0 && (lay->tri_offset % 8 || lay->stride % 8 || lay->tri_offset + 8 > lay->stride ||
+                                (lay->tri_offset < lay->color_offset + 16 && lay->color_offset < lay->tri_offset + 8))))
+    return fail(c, RTGPU_E_INVALID_PARAM, "pixel layout: a colour of four floats (4-byte aligned) and, if there is one, an 8-byte aligned pointer, inside the stride and apart");
+  return RTGPU_OK;
+}
+// the device copy of a caller's pixel records
+int ensure_map(rtgpu_ctx *c, size_t bytes) {
+  if (bytes <= c->h_cap_map) return RTGPU_OK;
+  c->h_cap_map = 0;
+  int rc = dev_alloc(c, &c->h_map, bytes);
+  if (rc) return rc;
+  c->h_cap_map = bytes;
+  return RTGPU_OK;
+}
+}  // namespace
+
+int rtgpu_render_pixelmap(rtgpu_ctx *c, void *map, const rtgpu_pixel_layout *lay, float *minmax) {
+  if (!c || !map) return RTGPU_E_INVALID_PARAM;
+  if (!c->have_frame) return fail(c, RTGPU_E_STATE, "rtgpu_frame_begin has not been called");
+  int rc = check_layout(c, lay);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t nt = rtgpu_tile_count(c, 0, 1), npx = (int64_t)c->cam.sw * c->cam.sh;
+  if ((size_t)nt > c->h_cap_tiles) {
+    c->h_cap_tiles = 0;
+    if ((rc = dev_alloc(c, &c->h_rgb_t, (size_t)nt * kTilePixels * 3)) || (rc = dev_alloc(c, &c->h_ids_t, (size_t)nt * kTilePixels))) return rc;
+    c->h_cap_tiles = (size_t)nt;
+  }
+  if (!c->h_mm && (rc = dev_alloc(c, &c->h_mm, 6))) return rc;
+  const size_t bytes = (size_t)npx * (size_t)lay->stride;
+  if ((rc = ensure_map(c, bytes)) || (rc = rtgpu_render(c, 0, 1, c->h_rgb_t, c->h_ids_t, c->h_mm))) return rc;
+  const PixelLayoutD ld{lay->stride, lay->color_offset, lay->tri_offset, lay->tri_base, lay->tri_stride};
+  KLAUNCH(c, k_pixelmap, dim3((unsigned)((npx + 255) / 256)), dim3(256), c->stream, (const float *)c->h_rgb_t, (const int32_t *)c->h_ids_t,
+          c->cam.sw, c->cam.sh, (int)tiles_x_of(c), ld, c->h_map);
+  HIPCHK(c, hipMemcpyAsync(map, c->h_map, bytes, hipMemcpyDeviceToHost, c->stream));
+  if (minmax) HIPCHK(c, hipMemcpyAsync(minmax, c->h_mm, sizeof(float) * 6, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RTGPU_OK;
+}
+
+int rtgpu_tonemap_pixelmap(rtgpu_ctx *c, const void *map, const rtgpu_pixel_layout *lay, int64_t n, const float *minmax, const float *gammas,
+                           int32_t ngammas, uint32_t *rgba) {
+  if (!c || !map || !minmax || !rgba || n < 0 || ngammas < 0 || (ngammas > 0 && !gammas)) return RTGPU_E_INVALID_PARAM;
+  int rc = check_layout(c, lay);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n == 0) return RTGPU_OK;
+  const size_t bytes = (size_t)n * (size_t)lay->stride;
+  if ((rc = ensure_map(c, bytes))) return rc;
+  if ((size_t)n > c->h_cap_tone) {
+    c->h_cap_tone = 0;
+    if ((rc = dev_alloc(c, &c->h_rgba, (size_t)n))) return rc;
+    c->h_cap_tone = (size_t)n;
+  }
+  if (!c->h_mm && (rc = dev_alloc(c, &c->h_mm, 6))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_map, map, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_mm, minmax, sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
+  if ((rc = tonemap_strided(c, reinterpret_cast<const float *>(c->h_map + lay->color_offset), lay->stride / 4, n, c->h_mm, gammas, ngammas, c->h_rgba))) return rc;
+  HIPCHK(c, hipMemcpyAsync(rgba, c->h_rgba, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RTGPU_OK;
+}
+
 int rtgpu_tonemap_host(rtgpu_ctx *c, const float *rgb, int64_t n, const float *minmax, float gamma, uint32_t *rgba) {
-  if (!c || !rgb || !minmax || !rgba || n < 0) return RTGPU_E_INVALID_PARAM;
+  return rtgpu_tonemap_multi_host(c, rgb, n, minmax, &gamma, 1, rgba);
+}
+
+int rtgpu_tonemap_multi_host(rtgpu_ctx *c, const float *rgb, int64_t n, const float *minmax, const float *gammas, int32_t ngammas, uint32_t *rgba) {
+  if (!c || !rgb || !minmax || !rgba || n < 0 || ngammas < 0 || (ngammas > 0 && !gammas)) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));
   int rc = RTGPU_OK;
   if ((size_t)n > c->h_cap_px) {  // (shares the row-major colour buffer of rtgpu_render_host)
@@ -1301,7 +1452,7 @@ int rtgpu_tonemap_host(rtgpu_ctx *c, const float *rgb, int64_t n, const float *m
   if (!c->h_mm && (rc = dev_alloc(c, &c->h_mm, 6))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->h_rgb, rgb, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_mm, minmax, sizeof(float) * 6, hipMemcpyHostToDevice, c->stream));
-  if ((rc = rtgpu_tonemap(c, c->h_rgb, n, c->h_mm, gamma, c->h_rgba))) return rc;
+  if ((rc = tonemap_strided(c, c->h_rgb, 3, n, c->h_mm, gammas, ngammas, c->h_rgba))) return rc;
   HIPCHK(c, hipMemcpyAsync(rgba, c->h_rgba, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return RTGPU_OK;

@@ -24,7 +24,8 @@ static void usage(const char *exe) {
          "    -I PATH  also write primary-hit triangle ids (int32, row-major, -1 = none)\n"
          "    -B PATH  binary cache of the geometry file (written if missing or older than its source)\n"
          "    --devices N  split the frame by 8x8 tiles over GPUs 0..N-1 (RCCL: colour range all-reduce, RGBA8 tile gather)\n"
-         "    --frames K   render K frames and report the time of a frame after the first\n", exe);
+         "    --frames K   render K frames and report the time of a frame after the first\n"
+         "    --gammas G1,G2,...  tone map averaged over a list of gammas (rtVisualizedSceneToBitmap's param1)\n", exe);
 }
 
 static char *join(const char *a, const char *b) {
@@ -38,12 +39,26 @@ int main(int argc, char **argv) {
   const char *letters = "glLacCsoGEDWHdIB";
   char *g, *l, *L, *a, *c, *C;
   float gamma = 2.5f, epsilon = 0.0f, distmod = 2.0f;
-  int i, devices = 0, frames = 1;
+  int i, devices = 0, frames = 1, ngammas = -1;
+  float gammas[65];
   if (argc <= 1) { usage(argv[0]); return 0; }
   for (i = 1; i < argc; i++) { /* value glued to the option ("-sPREFIX") or in the next argument */
     const char *arg = argv[i];
     if (!strcmp(arg, "--devices") && i + 1 < argc) { devices = atoi(argv[++i]); if (devices < 1) { fprintf(stderr, "--devices needs a positive number\n"); return 1; } continue; }
     if (!strcmp(arg, "--frames") && i + 1 < argc) { frames = atoi(argv[++i]); if (frames < 1) frames = 1; continue; }
+    if (!strcmp(arg, "--gammas") && i + 1 < argc) { /* zero-terminated, as src/raytrace.c:439-447 reads it; "," is the empty list */
+      const char *q = argv[++i];
+      ngammas = 0;
+      while (*q && ngammas < 64) {
+        char *end;
+        float v = strtof(q, &end);
+        if (end == q) break;
+        gammas[ngammas++] = v;
+        q = *end == ',' ? end + 1 : end;
+      }
+      gammas[ngammas] = 0.0f;
+      continue;
+    }
     if (arg[0] != '-' || !arg[1] || !strchr(letters, arg[1])) { fprintf(stderr, "unknown option %s\n", arg); return 1; }
     if (arg[2]) opt[(int)arg[1]] = arg + 2;
     else if (i + 1 < argc) opt[(int)arg[1]] = argv[++i];
@@ -120,7 +135,7 @@ int main(int argc, char **argv) {
    * path that worked, and the host layer's own codes are small positive numbers too. */
   int failed = 0;
   errno = 0;
-  RT_Bitmap *bmp = rtVisualizedSceneToBitmap(vs, F_HDR, NULL);
+  RT_Bitmap *bmp = rtVisualizedSceneToBitmap(vs, F_HDR, ngammas >= 0 ? gammas : NULL);
   if (!bmp) {
     fprintf(stderr, "problem while creating result image: %d, %s\n", errno, rtGetErrorDesc());
     failed = 1;

@@ -6,6 +6,7 @@
 #include "rt_host.h"
 
 #include <float.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -17,7 +18,40 @@ void rtHostSetDevice(int device) {
   g_device = device;
 }
 
+/* The pixel map (24 bytes per pixel: 199 MB for a 4K frame) is page-locked memory, which the GPU fills at the full rate of
+ * the host link, and is kept from call to call: pinning fresh pages for every frame costs more than the frame itself.  A
+ * block starts with a header that says how it was obtained; the map the caller sees lies 64 bytes behind it. */
+struct map_hdr { uint64_t magic; size_t bytes; int pinned; };
+#define MAP_MAGIC 0x52544d4150484452ull
+#define MAP_HDR 64
+static struct map_hdr *held_map; /* the block of the last destroyed frame, for the next one */
+static void block_free(struct map_hdr *h) {
+  if (!h) return;
+  if (h->pinned) rtgpu_pinned_free(h); else free(h);
+}
+static void *map_grab(size_t bytes) {
+  struct map_hdr *h = held_map;
+  held_map = NULL;
+  if (h && h->bytes < bytes) { block_free(h); h = NULL; }
+  if (!h) {
+    int pinned = 1;
+    h = rtgpu_pinned_alloc(bytes + MAP_HDR);
+    if (!h) { pinned = 0; h = malloc(bytes + MAP_HDR); }
+    if (!h) return NULL;
+    h->magic = MAP_MAGIC; h->bytes = bytes; h->pinned = pinned;
+  }
+  return (char *)h + MAP_HDR;
+}
+static void map_release(void *map) {
+  struct map_hdr *h;
+  if (!map) return;
+  h = (struct map_hdr *)((char *)map - MAP_HDR);
+  if (h->magic != MAP_MAGIC) return; /* not one of ours */
+  if (!held_map || held_map->bytes < h->bytes) { block_free(held_map); held_map = h; } else block_free(h);
+}
+
 void rtHostShutdown(void) {
+  block_free(held_map); held_map = NULL;
   if (g_ctx) { rtgpu_destroy(g_ctx); g_ctx = NULL; }
 }
 
@@ -41,20 +75,15 @@ static int gpu_error(rtgpu_ctx *ctx, int rc) {
   return rc;
 }
 
-
-/* The frame's big host buffers (colours, ids, the pixel map) are kept from call to call: fresh pages for 330 MB per 4K
- * frame cost more than the GPU frame itself.  grab() hands out the cached block if it is large enough (taking it out of
- * the cache), keep() puts a block back in place of a smaller or absent one. */
-struct held { void *p; size_t bytes; };
-static struct held held_rgb, held_ids, held_map;
-static void *grab(struct held *h, size_t bytes, int zero) {
-  void *p;
-  if (h->p && h->bytes >= bytes) { p = h->p; h->p = NULL; h->bytes = 0; if (zero) memset(p, 0, bytes); return p; }
-  return zero ? calloc(1, bytes ? bytes : 1) : malloc(bytes ? bytes : 1);
-}
-static void keep(struct held *h, void *p, size_t bytes) {
-  if (!p) return;
-  if (!h->p || h->bytes < bytes) { free(h->p); h->p = p; h->bytes = bytes; } else free(p);
+/* RT_VisualizedScenePixel as the GPU library is told about it (src/raytrace.h:23-27) */
+static rtgpu_pixel_layout pixel_layout(const RT_Scene *scene) {
+  rtgpu_pixel_layout l;
+  l.stride = (int64_t)sizeof(RT_VisualizedScenePixel);
+  l.color_offset = (int64_t)offsetof(RT_VisualizedScenePixel, c);
+  l.tri_offset = (int64_t)offsetof(RT_VisualizedScenePixel, t);
+  l.tri_base = scene ? (uint64_t)(uintptr_t)scene->t : 0;
+  l.tri_stride = (int64_t)sizeof(RT_Triangle);
+  return l;
 }
 
 RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera) {
@@ -64,24 +93,24 @@ RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera
   rtgpu_ctx *ctx;
   rtgpu_camera cam;
   rtgpu_grid_info gi;
-  float *rgb = NULL, *tri = NULL, mm[6];
-  int32_t *ids = NULL;
-  size_t p;
+  rtgpu_pixel_layout lay;
+  float *tri = NULL, mm[6];
   int k, ok = 0;
-  if (!res || !(res->map = grab(&held_map, (np ? np : 1) * sizeof *res->map, np == 0))) { errno = E_MEMORY; goto out; }
+  if (!res || !(res->map = map_grab((np ? np : 1) * sizeof *res->map))) { errno = E_MEMORY; goto out; }
+  if (np == 0) memset(res->map, 0, sizeof *res->map);
   res->width = camera->sw; res->height = camera->sh;
   res->gamma = scene->cfg.gamma > 0.0f ? scene->cfg.gamma : 2.5f; /* src/raytrace.c:333-337 */
   rtScenePreprocess(scene, camera);                               /* texture switch + texture coordinates */
   if (!(ctx = context())) goto out;
   if (!(flat = rtSceneFlatten(scene))) goto out;
   rtCameraFlatten(camera, &cam);
-  rgb = grab(&held_rgb, sizeof(float) * 3 * (np ? np : 1), 0);
-  ids = grab(&held_ids, sizeof(int32_t) * (np ? np : 1), 0);
+  lay = pixel_layout(scene);
   tri = malloc(sizeof(float) * 10 * (size_t)(scene->nt > 0 ? scene->nt : 1));
-  if (!rgb || !ids || !tri) { errno = E_MEMORY; goto out; }
+  if (!tri) { errno = E_MEMORY; goto out; }
+  /* (an upload of the scene the context already holds costs a comparison; the GPU writes the pixel map itself) */
   if (gpu_error(ctx, rtgpu_scene_upload(ctx, &flat->desc))) goto out;
   if (gpu_error(ctx, rtgpu_frame_begin(ctx, &cam))) goto out;
-  if (gpu_error(ctx, rtgpu_render_host(ctx, rgb, ids, mm))) goto out;
+  if (np > 0 && gpu_error(ctx, rtgpu_render_pixelmap(ctx, res->map, &lay, mm))) goto out;
   if (gpu_error(ctx, rtgpu_grid_info_get(ctx, &gi))) goto out;
   if (gpu_error(ctx, rtgpu_triangles_download(ctx, tri))) goto out;
   /* What the reference leaves behind in its arguments: preprocessed triangles (src/preprocess.c:19-32)
@@ -93,24 +122,21 @@ RT_VisualizedScene *rtVisualizedSceneRaytrace(RT_Scene *scene, RT_Camera *camera
   }
   for (k = 0; k < 3; k++) { scene->dmin[k] = gi.dmin[k]; scene->dmax[k] = gi.dmax[k]; }
   res->total_flux = gi.total_flux;
-  for (k = 0; k < 3; k++) { res->min.c[k] = mm[k]; res->max.c[k] = mm[3 + k]; }
+  /* (the reference leaves the pixels whose ray never enters the grid, and every pixel's fourth colour lane, as malloc
+   * handed them out, src/raytrace.c:323,381-382; here they are defined: 0) */
+  for (k = 0; k < 3; k++) { res->min.c[k] = np > 0 ? mm[k] : FLT_MAX; res->max.c[k] = np > 0 ? mm[3 + k] : FLT_MIN; }
   res->min.c[3] = FLT_MAX; res->max.c[3] = FLT_MIN;
-  for (p = 0; p < np; p++) {
-    res->map[p].c.c[0] = rgb[3 * p]; res->map[p].c.c[1] = rgb[3 * p + 1]; res->map[p].c.c[2] = rgb[3 * p + 2];
-    res->map[p].c.c[3] = 0.0f; /* (the reference's map comes from calloc) */
-    res->map[p].t = ids[p] >= 0 ? &scene->t[ids[p]] : NULL;
-  }
   ok = 1;
 out:
   rtSceneFlatFree(&flat);
-  keep(&held_rgb, rgb, sizeof(float) * 3 * (np ? np : 1)); keep(&held_ids, ids, sizeof(int32_t) * (np ? np : 1)); free(tri);
+  free(tri);
   if (!ok) rtVisualizedSceneDestroy(&res);
   return res;
 }
 
 void rtVisualizedSceneDestroy(RT_VisualizedScene **self) {
-  if (*self) {
-    keep(&held_map, (*self)->map, (size_t)((*self)->width > 0 ? (*self)->width : 0) * (size_t)((*self)->height > 0 ? (*self)->height : 0) * sizeof *(*self)->map);
+  if (self && *self) {
+    map_release((*self)->map);
     free(*self); *self = NULL;
   }
 }
@@ -118,23 +144,17 @@ void rtVisualizedSceneDestroy(RT_VisualizedScene **self) {
 RT_Bitmap *rtVisualizedSceneToBitmap(RT_VisualizedScene *s, int flags, void *param1) {
   const size_t np = (size_t)s->width * (size_t)s->height;
   RT_Bitmap *bmp = rtBitmapCreate(s->width, s->height, 0);
+  const rtgpu_pixel_layout lay = pixel_layout(NULL);
+  const float *gammas = param1 ? (const float *)param1 : &s->gamma; /* src/raytrace.c:439-440 */
+  int32_t ng = 0;
   rtgpu_ctx *ctx;
-  float *rgb, mm[6], gamma = s->gamma;
-  size_t p;
+  float mm[6];
   int k;
   if (!bmp) return NULL;
   if (!(flags & F_HDR)) return bmp; /* src/raytrace.c:437: nothing is drawn without F_HDR */
-  if (param1) { /* zero-terminated gamma list (src/raytrace.c:439-447); the GPU tone map takes one gamma */
-    const float *g = param1;
-    if (!(g[0] > 0.0f) || g[1] > 0.0f) { errno = E_INVALID_PARAM_VALUE; rtBitmapDestroy(&bmp); return NULL; }
-    gamma = g[0];
-  }
+  if (param1) { while (gammas[ng] > 0.0f) ng++; } else ng = s->gamma > 0.0f ? 1 : 0; /* the zero-terminated list, src/raytrace.c:445-447 */
   if (!(ctx = context())) { rtBitmapDestroy(&bmp); return NULL; }
-  rgb = grab(&held_rgb, sizeof(float) * 3 * (np ? np : 1), 0);
-  if (!rgb) { errno = E_MEMORY; rtBitmapDestroy(&bmp); return NULL; }
-  for (p = 0; p < np; p++) for (k = 0; k < 3; k++) rgb[3 * p + k] = s->map[p].c.c[k];
   for (k = 0; k < 3; k++) { mm[k] = s->min.c[k]; mm[3 + k] = s->max.c[k]; }
-  if (gpu_error(ctx, rtgpu_tonemap_host(ctx, rgb, (int64_t)np, mm, gamma, bmp->pixels))) rtBitmapDestroy(&bmp);
-  keep(&held_rgb, rgb, sizeof(float) * 3 * (np ? np : 1));
+  if (gpu_error(ctx, rtgpu_tonemap_pixelmap(ctx, s->map, &lay, (int64_t)np, mm, gammas, ng, bmp->pixels))) rtBitmapDestroy(&bmp);
   return bmp;
 }

@@ -54,6 +54,24 @@ LARGE = {
 }
 
 
+# gamma lists handed to the reference's rtVisualizedSceneToBitmap (its param1, src/raytrace.c:439-466) on the s3 frame of
+# CASES: the 8-bit images it writes (top row first, R G B)
+GAMMA_LISTS = [[2.5, 1.0], [1.0, 2.0, 3.0], [0.45, 2.2, 2.5, 4.0], [2.5, 2.5], [0.45], []]
+
+
+def gamma_lists():
+    prefix, over, (w, h), _ = CASES["s3"]
+    out = {}
+    for i, gl in enumerate(GAMMA_LISTS):
+        r = O.run_reference(os.path.join(ROOT, prefix), width=w, height=h, cwd=os.path.join(ROOT, "scenes"), want_bmp=True, gammas=gl)
+        bmp = r["bmp"]
+        img = np.frombuffer(bmp[54:], np.uint8).reshape(h, (w * 3 + 3) // 4 * 4)[:, :w * 3][::-1].reshape(h, w, 3)[:, :, ::-1]
+        out["img%d" % i] = np.ascontiguousarray(img)
+        out["bmp_sha256_%d" % i] = hashlib.sha256(bmp).hexdigest()
+        print("gamma list", gl, hashlib.sha256(bmp).hexdigest())
+    np.savez_compressed(os.path.join(HERE, "gamma_lists.npz"), lists=json.dumps(GAMMA_LISTS), case="s3", **out)
+
+
 def large(only=None):
     for name, (prefix, over, (w, h)) in LARGE.items():
         if only and name not in only:
@@ -71,6 +89,8 @@ def main():
     os.chdir(ROOT)
     if not O.have_reference():
         sys.exit("build oracle/_ref first: make -C oracle ref")
+    if len(sys.argv) > 1 and sys.argv[1] == "gammas":
+        return gamma_lists()         # make_golden.py gammas
     if len(sys.argv) > 1 and sys.argv[1] == "large":
         return large(sys.argv[2:])   # make_golden.py large [<case> ...]
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "only" else None   # make_golden.py only <case> ...
