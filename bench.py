@@ -227,7 +227,11 @@ def main():
     force = world == 1 and os.environ.get("RTGPU_BENCH_FORCE_COLLECTIVES") == "1"  # rehearsal of the N > 1 code on one GPU
     if world > 1 or force:
         if force:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+            import socket
+            with socket.socket() as sk:  # a port that is free now
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
             import raytracer_amd.dist as rdist
             rdist.FORCE_COLLECTIVES = True

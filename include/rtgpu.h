@@ -191,8 +191,8 @@ int64_t rtgpu_chunk_tile_limit(int fan, int levels, int nslots);
  * Asynchronous on the context's stream; rtgpu_sync waits. */
 int rtgpu_render(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax);
 
-/* No counterpart in the reference.  rtgpu_render for callers that cannot allocate device memory (code under HIP graph
- * capture, serving loops, harnesses that forbid hipMalloc): same arguments, same outputs bit for bit, but the queues of
+/* No counterpart in the reference.  rtgpu_render for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, code that records HIP graphs): same arguments, same outputs bit for bit, but the queues of
  * the pixel loop (hits, shaded-hit nodes, secondary rays, shadow results, partial colour ranges) live in a static device
  * array of rtgpu_static_scratch_bytes() = 64 MiB that every GPU the library runs on holds until the process ends; the
  * call makes no hipMalloc, hipFree or other allocating call (per-kernel "timing" is off for it: it would create events).
@@ -201,7 +201,12 @@ int rtgpu_render(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_i
  * lights (their random-number table is sized at run time) or a device index above 63 is refused with
  * RTGPU_E_UNSUPPORTED and a message that says which, before anything is enqueued.  All contexts of one GPU share that
  * GPU's array and it keeps the last call's contents (nothing in it has to be cleared: every entry is written before
- * it is read): calls that overlap on one GPU, from two contexts or two streams, race; calls on one stream do not. */
+ * it is read).  Calls that follow each other on the host are ordered on the device by the library, whichever contexts and
+ * streams they use (a call from another context or stream first waits for an event recorded behind the previous call);
+ * calls issued at the same time from several host threads race.  On a stream that is being captured the call enqueues its
+ * kernels and memsets and neither records nor waits for an event, so the library knows nothing of the launches of the
+ * resulting graph: the caller orders them against each other, against direct calls and against a later
+ * rtgpu_frame_begin (the tests do not cover capture and replay). */
 int rtgpu_render_static(rtgpu_ctx *ctx, int rank, int world, float *d_rgb, int32_t *d_ids, float *d_minmax);
 int64_t rtgpu_static_scratch_bytes(void);
 

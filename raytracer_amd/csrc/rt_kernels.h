@@ -20,9 +20,6 @@
 // the light (the kernels built with ENDS) it pays (ulica 1080p 116.5 against 118.9 ms without).
 #define RT_SHADOW_RAYCULL(RECTEST, ENDS) ((ENDS) || !(RECTEST))
 #endif
-#ifndef RT_OPAQUE_BUNDLE
-#define RT_OPAQUE_BUNDLE 1
-#endif
 #ifndef RT_WAVES_ACC
 #define RT_WAVES_ACC 4  // k_accumulate: 128 instead of 131 registers buy a fourth wave per SIMD (0.27 -> 0.23 ms); five spill (0.51 ms)
 #endif
@@ -111,14 +108,10 @@ RT_D float wave_max(float x) {
 }
 
 RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, float tz) {
-#ifdef RT_FIRST_LANE_LEADS
-  return __ffsll(m) - 1;
-#else
   const float key = alive ? __builtin_fmaxf(tx, __builtin_fmaxf(ty, tz)) : INFINITY;
   const float least = -wave_max(-key);
   const unsigned long long who = __ballot(alive && key == least);
   return __ffsll(who != 0 ? who : m) - 1;  // (a NaN key equals nothing: then the first lane of the mask)
-#endif
 }
 
 // The lane a visit's bundle is described about: the spreads about a ray in the middle of the group are about half of
@@ -126,20 +119,13 @@ RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, fl
 // 8x8 tile or the shadow rays of their hit points (lane = 8 y + x): the lane of the group nearest the tile's middle.
 // Otherwise the rays come in queue order (secondary rays, nodes ordered by the cell of their hit point), in which
 // neighbours lie close together: the lane of the group nearest the middle of the wavefront.
-#ifndef RT_CENTRAL
-#define RT_CENTRAL 1
-#endif
 RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
-#if RT_CENTRAL
   asm volatile("" : "+v"(lane));  // (the key is worked out per visit: as a loop invariant it would be spilled and reloaded)
   const int x2 = 2 * (lane & 7) - 7, y2 = 2 * (lane >> 3) - 7, l2 = 2 * lane - 63;
   const int off = tile ? x2 * x2 + y2 * y2 : (l2 < 0 ? -l2 : l2);
   const float key = in ? (float)(off * 64 + lane) : INFINITY;  // (an integer below 2^13: exact)
   const float least = -wave_max(-key);
   return least < INFINITY ? ((int)least & 63) : fallback;
-#else
-  return fallback;
-#endif
 }
 
 // The rays a wavefront walks through one cell, as a bundle around the leader's ray (direction axis, moment
@@ -155,9 +141,6 @@ RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
 // narrowing towards the light and a flat patch of hit points are accounted for by themselves (fan_slabs_pass).
 // c +- h: the box of the hit points; L: the light; smax >= every ray's s.  on = false: no fan (rays of several lights,
 // a planar light's samples, a NaN among the hit points, the nearest-hit walk).
-#ifndef RT_FAN
-#define RT_FAN 1
-#endif
 struct Fan { bool on; f3 c, h, rc, mc, L; float smax, hsum, lnorm; };  // c +- h: the box; rc = L - c, mc = c x rc; hsum = h.x + h.y + h.z, lnorm >= |L|
 struct Bundle { f3 axis; float rho; f3 m; float odr, onorm, ro, tmax, re, T; Fan fan; };
 RT_D Fan no_fan() { Fan f; f.on = false; f.c = f.h = f.rc = f.mc = f.L = mk3(0.0f, 0.0f, 0.0f); f.smax = f.hsum = f.lnorm = 0.0f; return f; }
@@ -536,11 +519,9 @@ RT_D bool fan_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float k1max, 
 // staging; without it every record of a kept batch is tested.  It pays where bundles are narrow against the triangles.
 // ENDS: the bundle's rays end (Bundle.re, .T are set) and the bundle test uses that.
 // RAYCULL: with the ray-by-ray test of the candidates' boxes (cull).
-// own_sub, own_mask: for a ticket shared by own_mask + 1 wavefronts, only the header chunks (256 records) whose index
-// & own_mask equals own_sub are looked at (0, 0: all of them).
 template <bool RECTEST, bool ENDS, bool RAYCULL, typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle_,
-                      bool transparent_counts_anywhere, uint32_t own_sub, uint32_t own_mask, Phases &ph, C &&cull, T &&tally, B &&batch,
+                      bool transparent_counts_anywhere, Phases &ph, C &&cull, T &&tally, B &&batch,
                       P &&pass1, F &&f, G &&more) {
   ph.template end<1>();
   asm volatile("" : "+v"(lane));  // (per-lane addresses below are worked out per visit instead of being kept, spilled, for the whole kernel)
@@ -550,23 +531,16 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
   const float4 *hsrc = reinterpret_cast<const float4 *>(g.cell_hdrs + hbeg);
   const uint32_t nb = (cnt + kBatch - 1) / kBatch;
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
-    if (((h0 / kHdrChunk) & own_mask) != own_sub) continue;  // a shared ticket: another wavefront tests this part of the list
-#if RT_OPAQUE_BUNDLE
     // The bundle's numbers are wave-uniform and live in scalar registers; their products with constants (axis / 511,
     // 1e-5 onorm, ...) are vector arithmetic, and hoisted out of this loop each holds a vector register for the whole
     // visit.  Opaque copies keep that arithmetic where it is used.
     Bundle bundle = bundle_;
     asm volatile("" : "+s"(bundle.axis.x), "+s"(bundle.axis.y), "+s"(bundle.axis.z), "+s"(bundle.rho), "+s"(bundle.ro), "+s"(bundle.onorm));
     asm volatile("" : "+s"(bundle.tmax), "+s"(bundle.odr));
-#if RT_FAN
     if (RECTEST && !ENDS && bundle.fan.on) {
       asm volatile("" : "+s"(bundle.fan.smax), "+s"(bundle.fan.hsum), "+s"(bundle.fan.lnorm));
     }
-#endif
     if (ENDS) asm volatile("" : "+s"(bundle.re), "+s"(bundle.T));
-#else
-    const Bundle &bundle = bundle_;
-#endif
     const int nh = (int)(nb - h0 < (uint32_t)kHdrChunk ? nb - h0 : (uint32_t)kHdrChunk);
     constexpr int kHdrVecs = kHdrFloats / 4;
     static_assert(kHdrChunk * kHdrVecs <= 192, "up to three 16-byte loads per lane stage a header chunk");
@@ -653,15 +627,8 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
             const RecB Rb = rec_b(R);
             const float *H = hs + b * kHdrFloats;
             const float kc_max = __builtin_fmaf(H[8], bundle.onorm, __builtin_fabsf(H[9])) + g.slack;
-#if RT_FAN == 2
-            if (!ENDS && bundle.fan.on) pass = fan_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[8], __builtin_fabsf(H[9]), bundle.fan);
-            else pass = bundle_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[10], bundle);
-#else
             pass = bundle_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[10], bundle);
-#if RT_FAN
             if (!ENDS && bundle.fan.on && pass) pass = fan_slabs_pass(A, Rb.ab, Rb.p, kc_max, H[8], __builtin_fabsf(H[9]), bundle.fan);
-#endif
-#endif
           }
         }
         const unsigned long long m = __ballot(pass);
@@ -1397,9 +1364,6 @@ RT_D Node plain_node(const ShadeP &sp, const Hit &h, f3 o, f3 r, int &sid) {
 // does not fit is parked in the lanes of a vector register and fetched back one v_readlane per word and use (in units
 // of the eight-word tuples it was loaded in).  The parts of a ticket outside its cell visits read what they need this
 // way; the opaque pointer keeps every read where it is written.
-#ifndef RT_FRESH_ARGS
-#define RT_FRESH_ARGS 1
-#endif
 template <typename T>
 RT_D T fresh_arg(size_t offset) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1413,7 +1377,7 @@ RT_D T fresh_arg(size_t offset) {
 }
 // k_nearest's arguments: one structure, so that a member's offset in it is its offset in the argument segment
 struct NearestArgs {
-  GridP g; const Ray *rays; Hit *hits; Ctl *ctl; int level; PrimaryP prim; SplitP split;
+  GridP g; const Ray *rays; Hit *hits; Ctl *ctl; int level; PrimaryP prim;
   ShadeP sp; Node *nodes; SOrigin *sorg; int node_base;  // for the instances that shade their hits themselves (FUSE)
 };
 template <bool COUNT, bool RECTEST, bool FUSE>
@@ -1424,7 +1388,6 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
   Ctl *__restrict__ ctl = args.ctl;
   const int level = args.level;
   const PrimaryP &prim = args.prim;
-  const SplitP &split = args.split;
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
@@ -1438,43 +1401,23 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
   Phases ph;
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
-  // tickets split.from.. are handed out split.ways times each (virtual tickets beyond the real ones)
-  const uint32_t real_tickets = ((uint32_t)nrays + 63u) / 64u;
-  const uint32_t split_from = split.from < real_tickets ? split.from : real_tickets;
-  Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
+  Tickets tickets((unsigned long long)nrays);
   for (;;) {
     uint32_t base;
-#if RT_FRESH_ARGS
     if (!tickets.take(ticket_counters(fresh_arg<Ctl *>(offsetof(NearestArgs, ctl)), 0, fresh_arg<int>(offsetof(NearestArgs, level))), lane, base)) break;
-#else
-    if (!tickets.take(ticket_counters(ctl, 0, level), lane, base)) break;
-#endif
-    uint32_t own_sub = 0, own_mask = 0, shared = 0;  // shared = index of the ticket among the shared ones
-    if ((base >> 6) >= split_from) {
-#if RT_FRESH_ARGS
-      const SplitP split = fresh_arg<SplitP>(offsetof(NearestArgs, split));
-#endif
-      const uint32_t q = (base >> 6) - split_from;
-      own_mask = split.ways - 1u; own_sub = q & own_mask; shared = q / split.ways;
-      base = 64u * (split_from + shared);
-    }
     RT_TICKET(TicketLog tl; tl.begin();)
     const int idx = base + lane;
     Ray ry;
     ry.i = -2;
     {  // (the ticket's rays, with its own copies of the arguments)
-#if RT_FRESH_ARGS
       const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
       const PrimaryP prim = fresh_arg<PrimaryP>(offsetof(NearestArgs, prim));
       const Ray *__restrict__ rays = fresh_arg<const Ray *>(offsetof(NearestArgs, rays));
-#endif
       if (idx < nrays) { if (prim.on) ry = primary_ray(prim, g, idx, true); else ry = rays[idx]; }
     }
     bool alive = ry.i >= 0;
-    if (own_sub == 0u) {  // (a shared ticket's pixels are counted once)
-      nPixels += __popcll(__ballot(ry.i != -2));
-      nTraced += __popcll(__ballot(alive));
-    }
+    nPixels += __popcll(__ballot(ry.i != -2));
+    nTraced += __popcll(__ballot(alive));
     const f3 o = ld3(ry.o), r = ld3(ry.r);
     f3 pm = mk3(0.0f, 0.0f, 0.0f);  // o x r, |o| and o.r: the ray's side of the filter and of the batch culling
     float onorm = 0.0f, odr = 0.0f;
@@ -1486,10 +1429,8 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
     w.cell = 0;
     uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
     if (alive) {
-#if RT_FRESH_ARGS
       const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
       const uint32_t *__restrict__ cstart = g.cell_start;
-#endif
       if (COUNT) nQ++;
       const int glo[3] = {0, 0, 0}, ghi[3] = {g.nv[0] - 1, g.nv[1] - 1, g.nv[2] - 1};
       walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, !COUNT, w);  // (the counting variant reports the reference's step counts)
@@ -1552,7 +1493,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
         proc = in_group;
         // lanes outside the cell test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
-        stream_cell<RECTEST, false, !RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle<false>(proc, o, r, pm, odr, onorm, best, INFINITY, central_lane(proc, lane, prim.on != 0, leader)), false, own_sub, own_mask, ph,
+        stream_cell<RECTEST, false, !RECTEST>(g, hbeg, beg, cnt, slice, lane, make_bundle<false>(proc, o, r, pm, odr, onorm, best, INFINITY, central_lane(proc, lane, prim.on != 0, leader)), false, ph,
                     [&](f3 c, float delta, f3 hw, float W) {
                       return wave_mask(proc & box_test_ray(c, delta, hw, W, r, pm, odr, best, false));
                     },
@@ -1574,8 +1515,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
                     [] { return true; });
       } else if (mode == kLaneMode) {
         proc = is_short;
-        static_assert(RT_SHORT_LIST <= (1 << kOwnShift), "a short list lies in one ownership unit: share 0 of a shared ticket tests it");
-        const uint32_t pn = proc && own_sub == 0u ? mycnt : 0u;
+        const uint32_t pn = proc ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
           if (i < pn) {
@@ -1593,7 +1533,6 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
         int cid = -1;
         uint32_t cpos = 0xffffffffu;
         for (uint32_t t0 = beg; t0 < beg + cnt; t0 += 64) {
-          if ((((t0 - beg) >> kOwnShift) & own_mask) != own_sub) continue;
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
           if (t < beg + cnt) {
@@ -1620,10 +1559,8 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
 #endif
       ph.end<7>();
       if (proc) {
-#if RT_FRESH_ARGS
         const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
         const uint32_t *__restrict__ cstart = g.cell_start;
-#endif
         if (best_id >= 0) {
           h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v;  // (its voxel: w.cell, where the walk now stays)
           alive = false;
@@ -1637,9 +1574,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
       }
       ph.end<6>();
     }
-#if RT_FRESH_ARGS
     Hit *__restrict__ hits = fresh_arg<Hit *>(offsetof(NearestArgs, hits));
-#endif
     // the ray's result: its hit record for k_hit, or (FUSE) the shaded hit and the origin of its shadow walks themselves
     auto emit = [&](const Hit &hh, Hit *__restrict__ out) {
       if (FUSE) {
@@ -1659,58 +1594,8 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
         out[idx] = hh;
       }
     };
-    if (own_mask != 0u) {
-#if RT_FRESH_ARGS
+    {
       const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
-      const PrimaryP prim = fresh_arg<PrimaryP>(offsetof(NearestArgs, prim));
-      const Ray *__restrict__ rays = fresh_arg<const Ray *>(offsetof(NearestArgs, rays));
-      const SplitP split = fresh_arg<SplitP>(offsetof(NearestArgs, split));
-#endif
-      // A shared ticket.  Every share walked the same cells in the same order and stopped a ray in the first cell in which
-      // one of ITS records gave a hit before the cell's exit distance; the reference stops in the first cell in which any
-      // record does, and takes the smallest (d, index) there: the smallest (steps, d, index) over the shares.  The key's
-      // d is non-negative (+ 0.0f turns -0 into +0), so its bits order like its value.
-      Ray ry2;  // the start voxel again (it was not kept through the walk): steps taken = steps possible at the start - steps left
-      ry2.i = -2;
-      if (idx < nrays) { if (prim.on) ry2 = primary_ray(prim, g, idx, true); else ry2 = rays[idx]; }
-      Walk w2;
-      w2.cell = 0; w2.nx = w2.ny = w2.nz = 0;
-      const int glo[3] = {0, 0, 0}, ghi[3] = {g.nv[0] - 1, g.nv[1] - 1, g.nv[2] - 1};
-      if (ry2.i >= 0) walk_init(g, o, r, ry2.i, ry2.j, ry2.k, glo, ghi, !COUNT, w2);
-      unsigned long long *slot = split.slots + 64ull * shared + lane;
-      unsigned long long key = ~0ull;
-      if (h.tri >= 0) {
-        const int hit_steps = (w2.nx + w2.ny + w2.nz) - (w.nx + w.ny + w.nz);
-        key = ((unsigned long long)hit_steps << 54) | ((unsigned long long)__float_as_uint(h.d + 0.0f) << 22) | (unsigned long long)h.tri;
-      }
-      unsigned long long seen = ~0ull;
-      if (key != ~0ull) seen = atomicMin(slot, key);
-      // (the returned values have arrived: every lane's key is in place before this share reports itself done.  The
-      // shares talk through read-modify-write atomics only, which are performed where all of them see each other, so no
-      // fence is needed: one would write back and invalidate this XCD's whole L2 per ticket)
-      const bool arrived = __ballot(seen == 1ull) != ~0ull;
-      uint32_t before = 0;
-      if (lane == 0 && arrived) before = atomicAdd(&split.done[shared], 1u);
-      before = __builtin_amdgcn_readfirstlane(before);
-      if (before == own_mask) {  // the last share of the ticket writes its hits
-        const unsigned long long k = atomicMin(slot, ~0ull);  // reads the slot where the other shares' atomics put it
-        h.tri = ry2.i >= 0 ? -1 : -2;
-        h.d = h.u = h.v = 0.0f; h.i = h.j = h.k = 0;
-        if (k != ~0ull) {
-          const int id = (int)(k & 0x3fffffull);
-          float d, u, v;
-          (void)exact_test(g, id, o, r, d, u, v);  // the same arithmetic on the same inputs as in the share that found it
-          h.tri = id; h.d = __uint_as_float((uint32_t)(k >> 22)); h.u = u; h.v = v;
-          for (int q = (int)(k >> 54); q > 0; q--) (void)walk_step(g, r, w2);
-          cell_to_voxel(g, w2.cell, h.i, h.j, h.k);
-        }
-        emit(h, hits);
-        nHits += __popcll(__ballot(h.tri >= 0));
-      }
-    } else {
-#if RT_FRESH_ARGS
-      const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
-#endif
       if (!FUSE && h.tri >= 0) cell_to_voxel(g, w.cell, h.i, h.j, h.k);
       emit(h, hits);
       nHits += __popcll(__ballot(h.tri >= 0));
@@ -2016,7 +1901,7 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 // k_shadow's arguments (one structure, like NearestArgs)
 struct ShadowArgs {
   GridP g; ShadeP sp; const SOrigin *sorg; const int32_t *rand_rank; float *ts_out; long long ts_stride; Ctl *ctl;
-  int level, node_base; SplitP split; const uint32_t *order;
+  int level, node_base; const uint32_t *order;
 };
 template <bool COUNT, bool RECTEST, bool ENDS>
 __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow(ShadowArgs args) {
@@ -2028,7 +1913,6 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
   const long long ts_stride = args.ts_stride;
   Ctl *__restrict__ ctl = args.ctl;
   const int level = args.level, node_base = args.node_base;
-  const SplitP &split = args.split;
   const uint32_t *__restrict__ order = args.order;
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
@@ -2043,27 +1927,10 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
   Phases ph;
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
-  // tickets split.from.. are handed out split.ways times each (only in scenes without transparent triangles: a
-  // transparency product has an order, a blocker has none)
-  const uint32_t real_tickets = (uint32_t)((total + 63) / 64);
-  const uint32_t split_from = split.from < real_tickets ? split.from : real_tickets;
-  Tickets tickets(64ull * (split_from + (unsigned long long)(real_tickets - split_from) * split.ways));
+  Tickets tickets((unsigned long long)total);
   for (;;) {
     uint32_t base;
-#if RT_FRESH_ARGS
     if (!tickets.take(ticket_counters(fresh_arg<Ctl *>(offsetof(ShadowArgs, ctl)), 1, fresh_arg<int>(offsetof(ShadowArgs, level))), lane, base)) break;
-#else
-    if (!tickets.take(ticket_counters(ctl, 1, level), lane, base)) break;
-#endif
-    uint32_t own_sub = 0, own_mask = 0, shared = 0;
-    if ((base >> 6) >= split_from) {
-#if RT_FRESH_ARGS
-      const SplitP split = fresh_arg<SplitP>(offsetof(ShadowArgs, split));
-#endif
-      const uint32_t q = (base >> 6) - split_from;
-      own_mask = split.ways - 1u; own_sub = q & own_mask; shared = q / split.ways;
-      base = 64u * (split_from + shared);
-    }
     RT_TICKET(TicketLog tl; tl.begin();)
     const long long item = (long long)base + lane;
     bool alive = false;
@@ -2076,7 +1943,6 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
     uint32_t mybeg = 0, mycnt = 0, myhbeg = 0;  // triangle list of the cell the walk stands in and its first batch header
     f3 light = mk3(0.0f, 0.0f, 0.0f);  // where this lane's ray ends
     {  // (the set-up of the ticket's walks, with its own copies of the arguments)
-#if RT_FRESH_ARGS
     const GridP g = fresh_arg<GridP>(offsetof(ShadowArgs, g));
     const ShadeP sp = fresh_arg<ShadeP>(offsetof(ShadowArgs, sp));
     const SOrigin *__restrict__ sorg = fresh_arg<const SOrigin *>(offsetof(ShadowArgs, sorg));
@@ -2084,7 +1950,6 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
     const uint32_t *__restrict__ order = fresh_arg<const uint32_t *>(offsetof(ShadowArgs, order));
     const int node_base = fresh_arg<int>(offsetof(ShadowArgs, node_base));
     const uint32_t *__restrict__ cstart = g.cell_start;
-#endif
     if (item < total) {
       // slot = item / n: one division per wavefront; its 64 items span at most two slots unless the queue is tiny
       const uint32_t slot0 = base / (uint32_t)n, rest = base - slot0 * (uint32_t)n + (uint32_t)lane;
@@ -2138,7 +2003,6 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
     // kernel its shadow walks took 114 instead of 107 ms, whichever tickets used it).  Built once per ticket, from all its
     // walks: the groups of its cell visits are nearly the whole ticket.
     Fan ticket_fan = no_fan();
-#if RT_FAN
     if (RECTEST && !ENDS && order == nullptr) {
       const unsigned long long walking = __ballot(alive);
       if (walking != 0) {
@@ -2148,7 +2012,6 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
           ticket_fan = make_fan(alive, a, lane_bcast3(light, first), wave_max(alive ? dmax : 0.0f) * 1.00001f);
       }
     }
-#endif
     ph.end<0>();
     for (;;) {
       const unsigned long long m = __ballot(alive);
@@ -2204,7 +2067,7 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
         Bundle bundle = make_bundle<ENDS>(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader));
         bundle.fan = ticket_fan;
         if (go)
-          stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, bundle, true, own_sub, own_mask, ph,
+          stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, bundle, true, ph,
                       [&](f3 c, float delta, f3 hw, float W) {
                         return wave_mask(in_group & (result >= 0.0f) & box_test_ray(c, delta, hw, W, r, pm, odr, dmax, true));
                       },
@@ -2238,7 +2101,7 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
         alive = alive & (result >= 0.0f);
       } else if (mode == kLaneMode) {
         proc = is_short;
-        uint32_t pn = proc && own_sub == 0u ? mycnt : 0u;  // (a short list lies in one ownership unit: share 0 tests it)
+        uint32_t pn = proc ? mycnt : 0u;
         for (uint32_t i = 0; __ballot(i < pn) != 0; ++i) {
           if (COUNT) { nWave++; if (i < pn) nLane++; }
           if (i < pn) {
@@ -2259,7 +2122,6 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
         float cts = lane_bcast(ts, leader);
         bool blocked = false;
         for (uint32_t t0 = beg; t0 < beg + cnt && !blocked; t0 += 64) {
-          if ((((t0 - beg) >> kOwnShift) & own_mask) != own_sub) continue;
           const uint32_t t = t0 + lane;
           if (COUNT) { nWave++; if (t < beg + cnt) nLane++; }
           int verdict = 0;
@@ -2286,10 +2148,8 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
 #endif
       ph.end<7>();
       if (proc && alive) {
-#if RT_FRESH_ARGS
         const GridP g = fresh_arg<GridP>(offsetof(ShadowArgs, g));
         const uint32_t *__restrict__ cstart = g.cell_start;
-#endif
         alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
         if (alive) {
           mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
@@ -2298,32 +2158,9 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
       }
       ph.end<6>();
     }
-#if RT_FRESH_ARGS
     float *__restrict__ ts_out = fresh_arg<float *>(offsetof(ShadowArgs, ts_out));
     const long long ts_stride = fresh_arg<long long>(offsetof(ShadowArgs, ts_stride));
-#endif
-    if (own_mask != 0u) {
-#if RT_FRESH_ARGS
-      const SplitP split = fresh_arg<SplitP>(offsetof(ShadowArgs, split));
-#endif
-      // A shared ticket (no transparent triangle in the scene, so ts stays 1): a ray is in shadow if any share found a
-      // blocker.  The shares OR their blocked rays into the ticket's mask; the one that finishes last writes the results.
-      unsigned long long *mask = split.slots + shared;
-      const unsigned long long mine = __ballot(result < 0.0f);
-      unsigned long long seen = 0;
-      if (lane == 0) seen = atomicOr(mask, mine);
-      const bool arrived = __ballot(seen == 1ull) != ~0ull;  // (the atomic has been performed before this share reports itself done)
-      uint32_t before = 0;
-      if (lane == 0 && arrived) before = atomicAdd(&split.done[shared], 1u);
-      before = __builtin_amdgcn_readfirstlane(before);
-      if (before == own_mask) {
-        unsigned long long all = 0;
-        if (lane == 0) all = atomicOr(mask, 0ull);  // reads the mask where the other shares' atomics put it
-        all = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(all >> 32)) << 32) |
-              (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)all);  // (readfirstlane gives a signed int)
-        if (have_result) ts_out[(long long)slot * ts_stride + where] = ((all >> lane) & 1ull) ? -1.0f : ts;
-      }
-    } else if (have_result) {
+    if (have_result) {
       // slot-major: the 64 lanes of a ticket are consecutive hits of one slot, so the store is one 256-byte line
 #ifdef RT_HIST
       ts_out[(long long)slot * ts_stride + where] = result < 0.0f ? result : ts;  // (diagnostic build: the blocker stays visible)

@@ -40,7 +40,6 @@ static_assert(kBatch == 8 || kBatch == 16 || kBatch == 32 || kBatch == 64, "a wa
 #endif
 constexpr int kHdrChunk = RT_HDR_CHUNK;  // batch headers staged in LDS at a time (one lane per header in the bundle test)
 static_assert(kHdrChunk == 32 || kHdrChunk == 64, "the masks of a header chunk are 64 bits wide");
-static_assert(kHdrChunk * kBatch == 256, "a header chunk covers 256 records: the unit by which shared tickets divide a list (kOwnShift)");
 constexpr int kHdrFloats = 20;
 
 // Header of one batch (positions kBatch*b .. kBatch*b + kBatch-1 of a cell's list): the axis-aligned box
@@ -151,18 +150,6 @@ struct Ctl {
   uint32_t pad[2 * kMaxLevels + 1];     // (the ticket counters of the walk kernels lie behind the block, 4 KB apart: ticket_counters)
   unsigned long long stat[32];
 };
-// Tickets of a walk kernel that are shared by several wavefronts ("ways", a power of two): tickets from..end of the
-// queue are each handed out `ways` times, and the wavefront that gets share `sub` of a ticket walks all 64 rays but
-// tests only the records it owns: positions p of a cell's list with (p / 256) % ways == sub.  The shares' results are
-// merged through `slots` (nearest walk: per ray a 64-bit key; shadow walk: per ticket a mask of blocked rays) and the
-// share that finishes last, told by `done`, writes the ticket's results.  from = 0xffffffff: no ticket is shared.
-struct SplitP {
-  uint32_t from, ways;
-  unsigned long long *slots;
-  uint32_t *done;
-};
-constexpr int kOwnShift = 8;  // records per ownership unit: one header chunk (kHdrChunk batches of kBatch records)
-
 struct QueueCaps { int32_t cap[kMaxLevels + 1]; };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
             kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests,

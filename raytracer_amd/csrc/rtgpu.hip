@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -27,6 +28,13 @@ constexpr size_t kScratchBytes = 64ull << 20;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 static void *g_scratch_ptr[kMaxDevices];  // device address of `scratch` on every device a context was created on
+// Every context of a GPU shares that GPU's array.  Who enqueued into it last, and an event recorded behind that call: a
+// call from another context or on another stream first makes its stream wait for that event, so that calls which
+// follow each other on the host do not overlap on the device whichever streams they use.  (Calls issued from several
+// host threads at once, and calls recorded under stream capture, are outside of this: see rtgpu_render_static.)
+struct ScratchOwner { const void *ctx = nullptr; hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool valid = false; };
+static ScratchOwner g_scratch_owner[kMaxDevices];
+static std::mutex g_scratch_mutex;
 
 namespace {
 
@@ -111,16 +119,11 @@ struct rtgpu_ctx {
   Hit *d_hits = nullptr;  // sized for the largest level
   Node *d_nodes = nullptr;
   SOrigin *d_sorg = nullptr;  // hit point + triangle of every node: what the shadow walk reads
-  // tickets shared by several wavefronts (SplitP): merge slots and arrival counters of the nearest and the shadow walk
-  unsigned long long *d_split_keys = nullptr, *d_split_masks = nullptr;
-  uint32_t *d_split_done_n = nullptr, *d_split_done_s = nullptr;
-  int opt_split_kernels = 3;  // option "split_kernels": bit 0 nearest walk, bit 1 shadow walk (diagnostic)
   int opt_record_test = 1;  // option "record_test": the bundle's record-level test in the walk kernels
   bool opt_fuse_hit = true; // option "fuse_hit": the nearest-hit walk shades its own hits where it can
   int opt_bundle_ends = -1;  // option "bundle_ends": the shadow walk's bundles narrow towards their lights; -1: in scenes with secondary rays
   bool mostly_opaque = true;  // fewer than half of the scene's triangles are transparent (kt > 0)
   bool any_specular = true;   // some surface a triangle uses has ks > 0 (k_accumulate's variant)
-  int opt_split = 0;  // option "split": 0 never, 1 as the queue length suggests, 2 / 4: every ticket, that many ways
   float *d_colors = nullptr, *d_ts = nullptr, *d_partial = nullptr;
   PrimaryP prim{};  // the chunk whose level-0 rays the kernels compute themselves (set by chunk_trace, used by chunk_shade)
   int32_t *d_rank = nullptr, *d_size = nullptr;  // planar lights: rand() replay rank of every node, hits per subtree
@@ -288,12 +291,6 @@ int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
   const size_t nrank = c->npl > 0 ? total : 1;
   if ((rc = give((void **)&c->d_rank, sizeof(int32_t) * nrank)) || (rc = give((void **)&c->d_size, sizeof(int32_t) * nrank))) return rc;
   if ((rc = give((void **)&c->d_order, sizeof(uint32_t) * (c->levels > 1 || c->opt_order > 1 ? total : 1)))) return rc;
-  // shared tickets exist only in scenes without secondary rays (one level, no transparent triangle)
-  const size_t st = c->fan == 0 ? tiles : 0, ss = st * (size_t)(c->shade.nslots > 0 ? c->shade.nslots : 1);
-  if ((rc = give((void **)&c->d_split_keys, sizeof(unsigned long long) * (st * kTilePixels + 1))) ||
-      (rc = give((void **)&c->d_split_masks, sizeof(unsigned long long) * (ss + 1))) ||
-      (rc = give((void **)&c->d_split_done_n, sizeof(uint32_t) * (st + 1))) || (rc = give((void **)&c->d_split_done_s, sizeof(uint32_t) * (ss + 1))))
-    return rc;
   return RTGPU_OK;
 }
 
@@ -331,7 +328,6 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
 // The chunk queues of a context, as a value: rtgpu_render_static puts the carved ones in and the context's own back.
 struct QueueSet {
   size_t chunk_tiles_cap, cap[kMaxLevels], base[kMaxLevels], total_nodes;
-  unsigned long long *d_split_keys, *d_split_masks; uint32_t *d_split_done_n, *d_split_done_s;
   Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; SOrigin *d_sorg; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size; uint32_t *d_order;
 };
 QueueSet take_queues(rtgpu_ctx *c) {
@@ -340,8 +336,6 @@ QueueSet take_queues(rtgpu_ctx *c) {
   for (int L = 0; L < kMaxLevels; L++) { q.cap[L] = c->cap[L]; q.base[L] = c->base[L]; q.d_rays[L] = c->d_rays[L]; c->d_rays[L] = nullptr; }
   q.d_hits = c->d_hits; q.d_nodes = c->d_nodes; q.d_sorg = c->d_sorg; q.d_colors = c->d_colors; q.d_ts = c->d_ts; q.d_partial = c->d_partial;
   q.d_rank = c->d_rank; q.d_size = c->d_size; q.d_order = c->d_order; c->d_order = nullptr;
-  q.d_split_keys = c->d_split_keys; q.d_split_masks = c->d_split_masks; q.d_split_done_n = c->d_split_done_n; q.d_split_done_s = c->d_split_done_s;
-  c->d_split_keys = c->d_split_masks = nullptr; c->d_split_done_n = c->d_split_done_s = nullptr;
   c->d_hits = nullptr; c->d_nodes = nullptr; c->d_sorg = nullptr; c->d_colors = c->d_ts = c->d_partial = nullptr; c->d_rank = c->d_size = nullptr;
   return q;
 }
@@ -350,7 +344,6 @@ void put_queues(rtgpu_ctx *c, const QueueSet &q) {
   for (int L = 0; L < kMaxLevels; L++) { c->cap[L] = q.cap[L]; c->base[L] = q.base[L]; c->d_rays[L] = q.d_rays[L]; }
   c->d_hits = q.d_hits; c->d_nodes = q.d_nodes; c->d_sorg = q.d_sorg; c->d_colors = q.d_colors; c->d_ts = q.d_ts; c->d_partial = q.d_partial;
   c->d_rank = q.d_rank; c->d_size = q.d_size; c->d_order = q.d_order;
-  c->d_split_keys = q.d_split_keys; c->d_split_masks = q.d_split_masks; c->d_split_done_n = q.d_split_done_n; c->d_split_done_s = q.d_split_done_s;
 }
 
 // The glibc rand() stream from seed 1, at least `need` values, on the device.
@@ -424,6 +417,14 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
       if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) { rtgpu_destroy(c); return RTGPU_E_NO_DEVICE; }
       g_scratch_ptr[device] = p;
     }
+    {
+      std::lock_guard<std::mutex> lock(g_scratch_mutex);
+      if (!g_scratch_owner[device].done && hipEventCreateWithFlags(&g_scratch_owner[device].done, hipEventDisableTiming) != hipSuccess) {
+        g_scratch_owner[device].done = nullptr;
+        rtgpu_destroy(c);
+        return RTGPU_E_NO_DEVICE;
+      }
+    }
     c->scratch = static_cast<unsigned char *>(g_scratch_ptr[device]);
   }
   hipDeviceProp_t prop;
@@ -458,7 +459,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   for (int L = 0; L < kMaxLevels; L++) dev_free(&c->d_rays[L]);
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba); dev_free(&c->d_gammas); dev_free(&c->h_map);
-  dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_order); dev_free(&c->d_split_keys); dev_free(&c->d_split_masks); dev_free(&c->d_split_done_n); dev_free(&c->d_split_done_s); dev_free(&c->d_ctl); dev_free(&c->d_totals);
+  dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_order); dev_free(&c->d_ctl); dev_free(&c->d_totals);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -490,8 +491,6 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "bundle_ends")) { if (value < -1 || value > 1) return fail(c, RTGPU_E_INVALID_PARAM, "bundle_ends: -1 (by the scene), 0 or 1"); c->opt_bundle_ends = (int)value; }
   else if (!strcmp(name, "order")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "order: 0, 1 or 2"); if ((int)value != c->opt_order) c->chunk_tiles_cap = 0; c->opt_order = (int)value; }
   else if (!strcmp(name, "order_parts")) { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RTGPU_E_INVALID_PARAM, "order_parts: 1, 2, 4 or 8"); c->opt_order_parts = (int)value; }
-  else if (!strcmp(name, "split_kernels")) c->opt_split_kernels = (int)value;
-  else if (!strcmp(name, "split")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, RTGPU_E_INVALID_PARAM, "split: 0, 1, 2 or 4"); c->opt_split = (int)value; }
   else if (!strcmp(name, "queue_margin")) { if (value < 1 || value > 100000) return fail(c, RTGPU_E_INVALID_PARAM, "queue_margin out of range"); c->queue_margin_permille = (int)value; }
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
@@ -787,24 +786,6 @@ unsigned node_blocks(size_t cap, int level) {
   return (unsigned)(level == 0 || b < 4096 ? (b ? b : 1) : 4096);
 }
 
-// Which tickets of a walk kernel are shared by several wavefronts.  A ticket is 64 rays and costs what its rays meet: on
-// temple the heaviest takes 15 times the average, and a walk kernel is not over before its slowest ticket is.  With
-// few tickets per wavefront (a small share of a frame: one rank of eight) every ticket is shared two or four ways;
-// with many, only the last eighth of the queue, which the wavefronts take one ticket at a time at the end of the walk.
-// Only in scenes without secondary rays (no transparent triangle: a blocker has no order, a transparency product
-// has), not while counting (the statistics are per ray), and within the widths of the merge key.
-SplitP plan_split(const rtgpu_ctx *c, long long tickets, int waves, unsigned long long *slots, uint32_t *done) {
-  SplitP s{0xffffffffu, 1u, slots, done};
-  const GridP &g = c->grid;
-  if (c->fan != 0 || c->opt_count || c->opt_split == 0 || tickets <= 0 || c->nt >= (1 << 22) || g.nv[0] + g.nv[1] + g.nv[2] >= 1000) return s;
-  if (c->opt_split >= 2) { s.from = 0; s.ways = (uint32_t)c->opt_split; return s; }
-  const long long per_wave = tickets / (waves > 0 ? waves : 1);
-  if (per_wave < 4) { s.from = 0; s.ways = 4; }
-  else if (per_wave < 12) { s.from = 0; s.ways = 2; }
-  else { s.from = (uint32_t)(tickets - tickets / 8); s.ways = 2; }
-  return s;
-}
-
 // One chunk of tiles, first half: primary rays, then nearest-hit walk and hit kernel level by level
 // (raytrace.c:170-204); with planar lights also the number of shaded hits in every node's subtree.
 int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
@@ -822,16 +803,6 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   }
   for (int L = 0; L < c->levels; L++) {
     const size_t capL = L == 0 ? (size_t)n0 : c->cap[L];
-    SplitP split{0xffffffffu, 1u, c->d_split_keys, c->d_split_done_n};
-    if (L == 0) {
-      const long long tickets = ((long long)n0 + 63) / 64;
-      if (c->opt_split_kernels & 1) split = plan_split(c, tickets, pgrid * 4, c->d_split_keys, c->d_split_done_n);
-      if (split.ways > 1) {
-        const size_t shared = (size_t)(tickets - split.from);
-        HIPCHK(c, hipMemsetAsync(c->d_split_keys, 0xff, sizeof(unsigned long long) * 64 * shared, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_split_done_n, 0, sizeof(uint32_t) * shared, c->stream));
-      }
-    }
     bool fused = false;
     {
       Span sp(c, W_NEAREST);
@@ -839,7 +810,7 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
       // A level that neither spawns rays nor meets a textured triangle shades its hits at the end of the walk: the hit
       // records do not go through memory and k_hit is not launched (option "fuse_hit").
       fused = c->opt_fuse_hit && !(L + 1 < c->levels) && c->tex_tri[0] < 0 && c->tex_tri[1] < 0 && c->tex_tri[2] < 0 && c->tex_tri[3] < 0;
-      const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued, split,
+      const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued,
                               c->shade, c->d_nodes, c->d_sorg, (int)c->base[L]};
 #define RT_LAUNCH_NEAREST(COUNT, RECTEST, FUSE) \
   KLAUNCH(c, (k_nearest<COUNT, RECTEST, FUSE>), dim3(pgrid), dim3(256), c->stream, nargs)
@@ -906,16 +877,6 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * (ends ? RT_WAVES_ENDS : RT_WAVES)) + 3) / 4);
   if (c->shade.nslots > 0) {
     for (int L = 0; L < c->levels; L++) {
-      SplitP split{0xffffffffu, 1u, c->d_split_masks, c->d_split_done_s};
-      if (L == 0) {
-        const long long tickets = ((long long)n0 * c->shade.nslots + 63) / 64;
-        if (c->opt_split_kernels & 2) split = plan_split(c, tickets, pgrid * 4, c->d_split_masks, c->d_split_done_s);
-        if (split.ways > 1) {
-          const size_t shared = (size_t)(tickets - split.from);
-          HIPCHK(c, hipMemsetAsync(c->d_split_masks, 0, sizeof(unsigned long long) * shared, c->stream));
-          HIPCHK(c, hipMemsetAsync(c->d_split_done_s, 0, sizeof(uint32_t) * shared, c->stream));
-        }
-      }
       Span sp(c, W_SHADOW);
       const uint32_t *order = level_order(c, L);
       if (order) {  // this level's nodes by the cell of their hit point
@@ -931,7 +892,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       }
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
-      const ShadowArgs sargs{c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], split, order};
+      const ShadowArgs sargs{c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], order};
 #define RT_LAUNCH_SHADOW(COUNT, RECTEST, ENDS) \
   KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, sargs)
 #define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)
@@ -1074,17 +1035,36 @@ int rtgpu_render_static(rtgpu_ctx *c, int rank, int world, float *d_rgb, int32_t
   const int timing = c->opt_timing;
   c->opt_timing = 0;  // (the per-kernel timing creates events: an allocating call)
   c->split_tiles = -1;
+  // Under stream capture the call only records work: no event of it may be waited for from outside the capture, so
+  // neither the array's owner nor the pipelined frame set-up learn of it (the caller orders a later
+  // rtgpu_frame_begin, and other users of the array, behind the graph's launches).
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (c->stream) (void)hipStreamIsCapturing(c->stream, &capture);
+  const bool capturing = capture != hipStreamCaptureStatusNone;
+  ScratchOwner &owner = g_scratch_owner[c->device];
   int rc = RTGPU_OK;
-  do {
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!capturing && owner.valid && (owner.ctx != c || owner.stream != c->stream) && hipStreamWaitEvent(c->stream, owner.done, 0) != hipSuccess)
+      rc = fail(c, RTGPU_E_NO_DEVICE, "rtgpu_render_static: cannot order the call behind the previous user of the scratch array");
+  }
+  if (!rc) do {
     hipLaunchKernelGGL(k_frame_init, dim3(1), dim3(64), 0, c->stream, d_minmax, c->d_totals);
     if (ntiles == 0) break;
     c->grid.slack = c->filter ? 0.0f : INFINITY;
     if ((rc = chunk_trace(c, 0, (int)ntiles, rank, world))) break;
     if ((rc = chunk_shade(c, 0, (int)ntiles, d_rgb, d_ids, d_minmax))) break;
-    mark_released(c);
+    if (capturing) c->released_valid[c->parity] = false; else mark_released(c);
   } while (0);
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    owner.valid = !capturing && hipEventRecord(owner.done, c->stream) == hipSuccess;
+    owner.ctx = c; owner.stream = c->stream;
+  }
   c->opt_timing = timing;
   put_queues(c, own);
+  // (c->fac[] keeps the worst-case factors this call planned with; rtgpu_render sets its own before it plans a chunk, and
+  // the context's own queues are judged by fac_alloc[], which this call has not touched)
   if (rc) return rc;
   HIPCHK(c, hipGetLastError());
   return RTGPU_OK;
@@ -1308,12 +1288,14 @@ int rtgpu_ticket_log(rtgpu_ctx *c, int which, uint32_t *out, int max_tickets, in
 int rtgpu_math_selfcheck(rtgpu_ctx *c, uint64_t mismatches[2]) {
   if (!c || !mismatches) return RTGPU_E_INVALID_PARAM;
   HIPCHK(c, hipSetDevice(c->device));
-  // the frame totals buffer is free between frames: two of its words serve as the counters
+  // two spare words at the end of the frame totals buffer serve as the counters (the frame's statistics stay as they are)
+  static_assert(kStatCount + kMaxLevels + 2 <= kTotals, "two spare words behind the statistics and the queue lengths");
+  unsigned long long *slots = c->d_totals + (kTotals - 2);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_totals, 0, sizeof(unsigned long long) * 2, c->stream));
-  KLAUNCH(c, k_math_selfcheck, dim3(c->num_cu * 8), dim3(256), c->stream, c->d_totals);
+  HIPCHK(c, hipMemsetAsync(slots, 0, sizeof(unsigned long long) * 2, c->stream));
+  KLAUNCH(c, k_math_selfcheck, dim3(c->num_cu * 8), dim3(256), c->stream, slots);
   unsigned long long bad[2] = {0, 0};
-  HIPCHK(c, hipMemcpyAsync(bad, c->d_totals, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(bad, slots, sizeof bad, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   mismatches[0] = bad[0]; mismatches[1] = bad[1];
   return RTGPU_OK;

@@ -128,37 +128,6 @@ def test_filter_counters(renderer):
         assert on[f + "_stage2"] >= on[f + "_stage3"] >= on[f + "_exact"]
 
 
-@pytest.mark.parametrize("prefix,over,w,h", [("scenes/temple/temple", {}, 640, 360), ("scenes/temple/temple", {}, 97, 61),
-                                               ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 160, 120),
-                                               ("scenes/s2/s2", {}, 160, 120)],
-                         ids=["temple_640x360", "temple_97x61", "test", "s2_planar"])
-def test_tickets_shared_by_several_wavefronts_do_not_change_the_frame(prefix, over, w, h):
-    """In scenes without secondary rays a ticket of the walk kernels can be shared by 2 or 4 wavefronts, each testing
-    its part of every cell's list, merged on (cells walked, distance, triangle index) resp. 'some share found a
-    blocker': ids, raw colours and colour range equal the unshared frame bit for bit, with every ticket shared 2 and 4
-    ways and with the automatic choice (small frames: every ticket)."""
-    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
-    scene = rt.Scene(os.path.join(ROOT, prefix), width=w, height=h, **over)
-    r = rt.Renderer(0)
-    try:
-        r.upload(scene)
-        frames = []
-        for split in (0, 2, 4, 1):
-            r.set_option("split", split)
-            for rep in range(2):
-                r.frame_begin()
-                frames.append(r.render_host())
-    finally:
-        r.close()
-    a = frames[0]
-    assert (a["ids"] >= 0).any()
-    for b in frames[1:]:
-        assert np.array_equal(a["ids"], b["ids"])
-        assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
-        assert np.array_equal(a["minmax"].view(np.uint32), b["minmax"].view(np.uint32))
-
-
-
 @pytest.mark.parametrize("prefix,over,w,h,tex", [c for c in CASES if "ulica" in c[0] or "pokoj" in str(c) or "s2/s2" in c[0] or c[2] == 333],
                          ids=lambda v: None)
 def test_order_of_shading_does_not_change_the_frame(renderer, prefix, over, w, h, tex):

@@ -78,3 +78,56 @@ def test_static_render_refuses_what_does_not_fit_and_leaves_the_context_usable()
         same(a, b)
     finally:
         r.close()
+
+
+def test_static_render_allocates_no_device_memory():
+    """The property in the entry point's name: free device memory is the same before and after a call (the first call of a
+    process loads nothing either: the kernels' code object came with the library)."""
+    import torch
+    r = rt.Renderer(0)
+    try:
+        scene = rt.Scene(os.path.join(ROOT, "scenes/ulica/ulica"), width=64, height=48)
+        r.upload(scene)
+        r.frame_begin()
+        n = r.tile_count() * 64
+        rgb = torch.zeros(n * 3, dtype=torch.float32, device="cuda"); ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+        mm = torch.zeros(6, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        r.render_static(rgb, ids, mm); r.sync()
+        for _ in range(3):
+            free0 = torch.cuda.mem_get_info()[0]
+            r.render_static(rgb, ids, mm); r.sync()
+            assert torch.cuda.mem_get_info()[0] == free0
+        # rtgpu_render on the same context does allocate (its queues), which is what the comparison is worth
+        free0 = torch.cuda.mem_get_info()[0]
+        r.render(rgb, ids, mm); r.sync()
+        assert torch.cuda.mem_get_info()[0] < free0
+    finally:
+        r.close()
+
+
+def test_static_render_from_two_contexts_on_two_streams_is_ordered_by_the_library():
+    """Two contexts of one GPU share the array.  Calls that follow each other on the host, each context on its own stream
+    and nothing waiting in between, do not overlap on the device: every frame is the one rtgpu_render gives."""
+    import torch
+    ra, rb = rt.Renderer(0), rt.Renderer(0)
+    try:
+        sa = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=640, height=360)
+        sb = rt.Scene(os.path.join(ROOT, "scenes/pokoj/s2"), width=96, height=72)
+        want_a, _ = frames(ra, sa)
+        want_b, _ = frames(rb, sb)
+        bufs = []
+        for r in (ra, rb):
+            n = r.tile_count() * 64
+            bufs.append([(torch.zeros(n * 3, dtype=torch.float32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"),
+                          torch.zeros(6, dtype=torch.float32, device="cuda")) for _ in range(3)])
+        torch.cuda.synchronize()
+        for k in range(3):  # a, b, a, b, a, b: enqueued back to back
+            ra.render_static(*bufs[0][k])
+            rb.render_static(*bufs[1][k])
+        ra.sync(); rb.sync()
+        for k in range(3):
+            same(want_a, tuple(t.cpu().numpy() for t in bufs[0][k]))
+            same(want_b, tuple(t.cpu().numpy() for t in bufs[1][k]))
+    finally:
+        ra.close(); rb.close()
