@@ -22,7 +22,7 @@ $(PKG)/librthost.so: $(HOSTSRC) $(PKG)/host/rt_host.h include/rtgpu.h $(PKG)/lib
 
 # the N-GPU host (one process, RCCL): its own library, loaded by the command line only for --devices
 $(PKG)/librtmulti.so: $(PKG)/host/multigpu.c $(PKG)/host/rt_host.h include/rtgpu.h $(PKG)/librthost.so
-	$(CC) $(CFLAGS) -I$(ROCM)/include -shared -o $@ $< -L$(PKG) -lrthost -lrtgpu -L$(ROCM)/lib -lrccl -lamdhip64 -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib -lm
+	$(CC) $(CFLAGS) -I$(ROCM)/include -shared -o $@ $< -L$(PKG) -lrthost -lrtgpu -L$(ROCM)/lib -lrccl -lamdhip64 -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib -lm -lpthread
 
 $(PKG)/raytrace: $(PKG)/host/main.c $(PKG)/librthost.so
 	$(CC) $(CFLAGS) -o $@ $< -L$(PKG) -lrthost -lrtgpu -Wl,-rpath,'$$ORIGIN' -lm -ldl

@@ -214,13 +214,17 @@ int64_t rtgpu_static_scratch_bytes(void);
  * pixel order (src/raytrace.c:241-262, each pixel's ray tree in post-order), so a rank has to know how many shaded
  * hits the pixels before its own have, on whichever rank they are:
  *   rtgpu_render_trace   primary rays, nearest-hit walks and hit kernels of this rank's tiles (one chunk);
- *   rtgpu_hit_counts     d_counts[rtgpu_tile_count(rank, world) * 64]: shaded hits per pixel of this rank, tile-major;
+ *   rtgpu_hit_counts     d_counts[rtgpu_tile_count(rank, world) * 64]: shaded hits per pixel of this rank, tile-major
+ *                        (rtgpu_hit_total: their sum);
  *   (the host gathers every rank's counts: d_all_counts[world][per_rank], per_rank >= the largest share, and
  *    their sum total_hits)
  *   rtgpu_render_shade   rand() order, shadow walks, colours, colour range: the outputs of rtgpu_render.
  * Without planar lights, or with world = 1, d_all_counts may be NULL and the pair equals rtgpu_render. */
 int rtgpu_render_trace(rtgpu_ctx *ctx, int rank, int world);
 int rtgpu_hit_counts(rtgpu_ctx *ctx, int32_t *d_counts);
+/* ... and their sum, this rank's shaded hits of all recursion levels, as one 64-bit integer in device memory: a host
+ * adds the ranks' sums up with a collective instead of downloading the counts (total_hits of rtgpu_render_shade). */
+int rtgpu_hit_total(rtgpu_ctx *ctx, int64_t *d_total);
 int rtgpu_render_shade(rtgpu_ctx *ctx, const int32_t *d_all_counts, int64_t per_rank, int64_t total_hits, float *d_rgb,
                        int32_t *d_ids, float *d_minmax);
 

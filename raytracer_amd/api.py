@@ -147,6 +147,7 @@ def gpu_lib():
         L.rtgpu_chunk_tile_limit.argtypes = [i32, i32, i32]
         L.rtgpu_render_trace.argtypes = [vp, i32, i32]
         L.rtgpu_hit_counts.argtypes = [vp, vp]
+        L.rtgpu_hit_total.argtypes = [vp, vp]
         L.rtgpu_render_shade.argtypes = [vp, vp, i64, i64, vp, vp, vp]
         L.rtgpu_tonemap.argtypes = [vp, vp, i64, vp, C.c_float, vp]
         L.rtgpu_tonemap_multi.argtypes = [vp, vp, i64, vp, C.POINTER(C.c_float), i32, vp]
@@ -375,6 +376,10 @@ class Renderer:
 
     def hit_counts(self, counts):
         self._chk(self._L.rtgpu_hit_counts(self._h, _ptr(counts)), "rtgpu_hit_counts")
+
+    def hit_total(self, total):
+        """total: a device int64 that receives this rank's number of shaded hits (the sum of hit_counts)."""
+        self._chk(self._L.rtgpu_hit_total(self._h, _ptr(total)), "rtgpu_hit_total")
 
     def render_shade(self, rgb, ids, minmax, all_counts=None, per_rank=0, total_hits=-1):
         self._chk(self._L.rtgpu_render_shade(self._h, _ptr(all_counts) if all_counts is not None else None, per_rank, total_hits,

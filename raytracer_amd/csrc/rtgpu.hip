@@ -1101,6 +1101,17 @@ int rtgpu_hit_counts(rtgpu_ctx *c, int32_t *d_counts) {
   return RTGPU_OK;
 }
 
+int rtgpu_hit_total(rtgpu_ctx *c, int64_t *d_total) {
+  if (!c || !d_total) return RTGPU_E_INVALID_PARAM;
+  if (c->split_tiles < 0) return fail(c, RTGPU_E_STATE, "rtgpu_render_trace has not been called for this frame");
+  HIPCHK(c, hipSetDevice(c->device));
+  static_assert(sizeof(unsigned long long) == sizeof(int64_t), "the statistics are 64-bit words");
+  // the walks of every level add their hits to one counter of the chunk's control block (a rank's share is one chunk here)
+  if (c->split_tiles == 0) HIPCHK(c, hipMemsetAsync(d_total, 0, sizeof(int64_t), c->stream));
+  else HIPCHK(c, hipMemcpyAsync(d_total, &c->d_ctl->stat[kShaded], sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+  return RTGPU_OK;
+}
+
 int rtgpu_render_shade(rtgpu_ctx *c, const int32_t *d_all_counts, int64_t per_rank, int64_t total_hits, float *d_rgb, int32_t *d_ids,
                        float *d_minmax) {
   if (!c || !d_rgb || !d_ids || !d_minmax) return RTGPU_E_INVALID_PARAM;

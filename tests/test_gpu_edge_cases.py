@@ -300,6 +300,40 @@ def test_command_line_devices_1_issues_the_collectives_and_writes_the_reference_
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == k["bmp_sha256"]
 
 
+@pytest.mark.parametrize("name,ndev,depth", [("s3", 3, 1), ("s3", 2, 2), ("s2", 3, 1), ("temple", 4, 2), ("ulica", 3, 2)])
+def test_command_line_devices_n_rehearsed_on_one_gpu(tmp_path, name, ndev, depth):
+    """`raytrace --devices N` with RTGPU_LOOPBACK=1: N ranks (contexts, streams, one host thread each) on the one GPU of
+    the box, the collectives replaced by copies on that GPU.  The image is the reference's (s3, s2 with its planar light
+    and the hit-count exchange, temple; ulica at 192x108: the single-device command line's), and the per-device calls of
+    a frame run side by side: rank 1's call has started before rank 0's has returned, in every frame, although
+    rtgpu_render waits for its device once per chunk in scenes with secondary rays (s3, ulica)."""
+    import re
+    exe = os.path.join(ROOT, "raytracer_amd", "raytrace")
+    out = str(tmp_path / "o.bmp")
+    if name == "ulica":
+        args = ["-s", os.path.join(ROOT, "scenes/ulica/ulica"), "-W", "192", "-H", "108"]
+        one = str(tmp_path / "one.bmp")
+        p = subprocess.run([exe] + args + ["-o", one], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        want = hashlib.sha256(open(one, "rb").read()).hexdigest()
+    else:
+        args = ["-s", os.path.join(ROOT, KNOWN[name]["prefix"])]
+        want = KNOWN[name]["bmp_sha256"]
+    frames = 5
+    p = subprocess.run([exe] + args + ["-o", out, "--devices", str(ndev), "--frames", str(frames)], cwd=str(tmp_path),
+                       env=dict(os.environ, RTGPU_LOOPBACK="1", RTGPU_TRACE="1", RTGPU_FRAMES_IN_FLIGHT=str(depth)),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == want
+    calls = {}
+    for f, r, job, a, b in re.findall(r"trace: frame (\d+) rank (\d+) (.*?): started ([0-9.]+) ms, returned ([0-9.]+) ms", p.stderr):
+        if "shade" not in job:
+            calls[(int(f), int(r))] = (float(a), float(b))
+    assert len(calls) == frames * ndev
+    for f in range(frames):
+        assert calls[(f, 1)][0] < calls[(f, 0)][1], (f, calls[(f, 0)], calls[(f, 1)])
+
+
 def test_command_line_devices_beyond_the_node_is_an_error(tmp_path):
     exe = os.path.join(ROOT, "raytracer_amd", "raytrace")
     p = subprocess.run([exe, "-s", os.path.join(ROOT, "scenes/s3/s3"), "-o", str(tmp_path / "o.bmp"), "--devices", "64"], cwd=str(tmp_path),
