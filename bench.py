@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the per-pixel trace path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene temple] [--width 3840 --height 2160]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene temple] [--width 3840 --height 2160] [--no-config5]
 
 Workload (N=1 and N>1 alike): scenes/temple at 3840x2160, the configuration the headline metric is
 quoted on.  One step = one frame = everything the reference's rtVisualizedSceneRaytrace +
@@ -12,14 +12,18 @@ the timed region; the finished image stays in HBM on rank 0.  The frame is split
 the ranks, so total work is fixed as N grows ("strong" scaling).  With N > 1 two frames are in flight on every GPU
 (raytracer_amd.dist.FramePipeline: each in its own context and stream; a frame's exchange and the latency-bound end of
 its walk kernels run under the other frame's kernels; one GPU renders one frame at a time, so that a kernel's launch time
-is its own: three in flight there give 5.55 -> 5.45 ms per frame); all K frames are complete when the
-timed region ends, and ms_per_step is the region's length / K.  config.frames_in_flight says how many,
---frames-in-flight overrides; frame_latency_ms is one frame alone, start to finish (barriers included).
+is its own); all K frames are complete when the timed region ends, and ms_per_step is the region's length / K.
+config.frames_in_flight says how many, --frames-in-flight overrides; frame_latency_ms is one frame alone, start to
+finish (barriers included).
 
 metric = Mrays/s, rays counted as the reference issues them (nearest-hit queries + shadow queries,
 back-face early-outs included): 40,689,192 per temple 4K frame.
 
 Extra objects on the JSON line:
+  config5       the baseline's fifth configuration, scenes/ulica with 64 lights and secondary rays to depth 5, on the same
+                ranks with the same exchange: "ulica_1920x1080" (three timed frames) and "ulica_7680x4320" (one timed
+                frame: 33 M pixels, 5.5 G rays), each with value, ms_per_step, rays_per_frame, the per-kernel table and
+                its own roofline object; and the reference timed on the same scene at 160x90 (cpu_baseline).
   roofline      the dominant kernel (shadow or nearest walk) against the bound that holds it, VALU issue: the
                 scene is cache-resident, nothing is a dense contraction, and a SIMD issues one wave64 VALU
                 instruction per two cycles.  frac = 2 x SQ_INSTS_VALU / (cycles x 1024 SIMDs) of one launch,
@@ -30,10 +34,11 @@ Extra objects on the JSON line:
                 (64 B per ray + 8 B per visited voxel + 40 B per listed triangle over the launch time: what a
                 walk that read every listed triangle from memory would move; most of it is culled and the rest
                 is served by LDS and L2, so this is no fraction of any peak).  The launch time is measured in
-                this run (HIP events on the launch stream); the counter values come from the rocprofv3 --pmc
-                passes kept under profiles/ (a profiler cannot run inside the timed region), which carry the
-                SHA-256 of raytracer_amd/csrc/* they were collected on: if that differs from this tree's the
-                counter-derived fields are null and "stale" is true.
+                this run (HIP events on the launch stream; a frame of ulica launches the kernel once per recursion
+                level and chunk: the mean over those launches, like the counters); the counter values come from the
+                rocprofv3 --pmc passes kept under profiles/ (pmc*.json, traffic*.json: a profiler cannot run inside the
+                timed region), one pair of files per workload, which carry the SHA-256 of raytracer_amd/csrc/* they were
+                collected on: if that differs from this tree's the counter-derived fields are null and "stale" is true.
   cpu_baseline  the unmodified reference (oracle/_ref/ref_dump) or, if that binary is absent, the C
                 oracle, single-threaded on the host, on the same scene at a reduced resolution;
                 cpu_baseline.parallel is the C oracle on the same sample with its rows spread over the
@@ -114,34 +119,32 @@ def launch_ranks(args, argv, script=None):
     return 0
 
 
-def counter_profile(fam):
-    """Counter values of one launch of k_<fam> from the rocprofv3 passes kept under profiles/ (SQ counters in pmc.json,
-    L2 memory-side counters in traffic.json), or None for a file that is missing or was collected on other kernel
-    sources than this tree's."""
+def counter_profile(fam, workload):
+    """Counter values of one launch of k_<fam> for `workload` ("temple 3840x2160") from the rocprofv3 passes kept under
+    profiles/ (SQ counters in pmc*.json, L2 memory-side counters in traffic*.json; the file whose "workload" member says
+    so), or None for a file that is missing or was collected on other kernel sources than this tree's."""
+    import glob
     import raytracer_amd as rt
     have = rt.csrc_hash()
     out = {}
-    for key, name in (("pmc", "pmc.json"), ("traffic", "traffic.json")):
+    for key, pattern in (("pmc", "pmc*.json"), ("traffic", "traffic*.json")):
         out[key] = None
-        try:
-            j = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except Exception:
-            continue
-        if j.get("csrc_sha256") == have and ("k_" + fam) in j:
-            out[key] = dict(j["k_" + fam], workload=j.get("workload"))
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
+            try:
+                j = json.load(open(path))
+            except Exception:
+                continue
+            if j.get("workload") == workload and j.get("csrc_sha256") == have and ("k_" + fam) in j:
+                out[key] = dict(j["k_" + fam], workload=j.get("workload"), file=os.path.basename(path))
     return out
 
 
 def roofline(fam, avg_ms, q, S, T, full_tests, lane_slots, workload):
     """The roofline object of the dominant walk kernel (see the module docstring)."""
     secs = avg_ms * 1e-3
-    prof = counter_profile(fam)
+    # the counters describe the launches of whole frames of one workload on one GPU (workload None: a rank's share, no counters)
+    prof = counter_profile(fam, workload) if workload else {"pmc": None, "traffic": None}
     pm, tr = prof["pmc"], prof["traffic"]
-    # the counters describe whole-frame launches of the default workload on one GPU
-    if pm is not None and pm.get("workload") != workload:
-        pm = None
-    if tr is not None and tr.get("workload") != workload:
-        tr = None
     out = {"bound": "valu_issue", "kernel": "k_" + fam, "achieved": None, "peak": None, "unit": "G wave-instructions/s",
            "frac": None, "traffic": None, "hbm_frac": None, "hbm_gbs": None, "l2_gbs": None, "l2_hit_rate": None,
            "avg_launch_ms": round(avg_ms, 4), "stale": pm is None or tr is None}
@@ -187,63 +190,20 @@ def roofline(fam, avg_ms, q, S, T, full_tests, lane_slots, workload):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default="temple")
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 1 on one GPU, 2 on several")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-width", type=int, default=960)
-    ap.add_argument("--cpu-height", type=int, default=540)
-    args = ap.parse_args()
+SCENES = {"temple": ("scenes/temple/temple", {}), "ulica": ("scenes/ulica/ulica", {}), "s3": ("scenes/s3/s3", {}),
+          "s5": ("scenes/s5/s5", {}), "pokoj": ("scenes/pokoj/s2", {}), "s2": ("scenes/s2/s2", {})}
 
-    # Before anything touches torch or the GPU: a plain `python bench.py --gpus N` starts its own ranks.
-    if "WORLD_SIZE" not in os.environ:
-        if args.gpus > 1:
-            sys.exit(launch_ranks(args, sys.argv[1:]))
-    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
-        sys.exit("bench.py: WORLD_SIZE=%s but --gpus %d" % (os.environ["WORLD_SIZE"], args.gpus))
 
-    # Libraries below write banners to the C-level stdout (RCCL prints its version when a communicator is made); the
-    # one JSON line is the only thing this program may print there, so stdout points to stderr until that line.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-
-    import torch
-    import torch.distributed as dist
-    import raytracer_amd as rt
-    from raytracer_amd.dist import FramePipeline, default_depth
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    force = world == 1 and os.environ.get("RTGPU_BENCH_FORCE_COLLECTIVES") == "1"  # rehearsal of the N > 1 code on one GPU
-    if world > 1 or force:
-        if force:
-            import socket
-            with socket.socket() as sk:  # a port that is free now
-                sk.bind(("127.0.0.1", 0))
-                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-            import raytracer_amd.dist as rdist
-            rdist.FORCE_COLLECTIVES = True
-        dist.init_process_group("nccl", device_id=dev)
-
-    scenes = {"temple": ("scenes/temple/temple", {}), "ulica": ("scenes/ulica/ulica", {}), "s3": ("scenes/s3/s3", {}),
-              "s5": ("scenes/s5/s5", {}), "pokoj": ("scenes/pokoj/s2", {}), "s2": ("scenes/s2/s2", {})}
-    prefix, over = scenes[args.scene]
+def run_leg(env, scene_name, width, height, steps, warmup, depth, latency_reps=3):
+    """One workload on this job's ranks: a counting pass (rays per frame, S and T), `warmup` frames with HIP events around
+    every kernel family, exactly `steps` timed frames between barriers, then `latency_reps` single frames start to finish.
+    Returns the workload's result object on rank 0 (the members the top-level line and the config5 legs share), None
+    on the other ranks."""
+    torch, dist, rt, dev, rank, world, local_rank = (env[k] for k in ("torch", "dist", "rt", "dev", "rank", "world", "local_rank"))
+    from raytracer_amd.dist import FramePipeline
+    prefix, over = SCENES[scene_name]
     prefix = os.path.join(ROOT, prefix)
-    scene = rt.Scene(prefix, width=args.width, height=args.height, **over)
-    # Frames in flight on this rank's GPU (FramePipeline): one on a single GPU, two where a rank renders a share of the frame
-    depth = args.frames_in_flight if args.frames_in_flight > 0 else default_depth(world)
+    scene = rt.Scene(prefix, width=width, height=height, **over)
     pipe = FramePipeline(lambda: rt.Renderer(local_rank), scene, rank, world, depth)
     renderer = pipe.renderers[0]
 
@@ -263,7 +223,7 @@ def main():
     # Warm-up frames carry HIP events around every kernel family (the per-kernel table of the result line); the timed
     # frames only around the two walk kernels, whose launch time the roofline object needs: the events of a whole frame
     # cost 0.07 ms of a 5.5 ms frame.
-    nwarm = max(args.warmup, depth if depth > 1 else 0)
+    nwarm = max(warmup, depth if depth > 1 else 0)
     renderer.set_option("timing", 1)
     renderer.timings()
     for _ in range(nwarm):
@@ -273,17 +233,19 @@ def main():
     warm_frames = (nwarm + depth - 1) // depth  # frames of the warm-up that ran in slot 0
     renderer.set_option("timing", 2)
     pipe.issued = 0
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         pipe.frame()
     barrier()
     elapsed = time.perf_counter() - t0
     tim = renderer.timings().asdict()
-    timed_frames = (args.steps + depth - 1) // depth  # frames of the timed region that ran in slot 0, whose kernels are timed
+    chunks = renderer.counters().asdict()
+    timed_frames = (steps + depth - 1) // depth  # frames of the timed region that ran in slot 0, whose kernels are timed
 
     # one frame alone on the GPU(s), start to finish: what a caller that waits for every frame sees
     latency = None
-    for _ in range(3):
+    for _ in range(latency_reps):
         barrier()
         t1 = time.perf_counter()
         with torch.cuda.stream(pipe.streams[0]):
@@ -299,57 +261,146 @@ def main():
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     rays_frame = float(rays_t.item())
+    pipe.close()
+    del pipe
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        # dominant kernel on this rank
-        fam = "shadow" if tim["shadow_ms"] >= tim["nearest_ms"] else "nearest"
-        launches = max(tim[fam + "_launches"], 1)
-        avg_ms = tim[fam + "_ms"] / launches
-        if fam == "shadow":
-            q, S, T = cnt["shadow_queries"], cnt["shadow_steps"], cnt["shadow_tests"]
-        else:
-            q, S, T = cnt["nearest_queries"], cnt["nearest_steps"], cnt["nearest_tests"]
-        per_launch = timed_frames / launches  # frames per launch of this family (1 when the frame is one chunk)
-        full = cnt[fam + "_full_tests"]
-        workload = "%s %dx%d" % (args.scene, args.width, args.height)
-        roof = roofline(fam, avg_ms, q * per_launch, S * per_launch, T * per_launch, full * per_launch,
-                        cnt[fam + "_lane_slots"] * per_launch, workload if world == 1 else None)
-        out = {
-            "metric": "Mrays/s (primary+secondary)", "value": round(rays_frame * args.steps / elapsed / 1e6, 3),
-            "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 3), "frame_latency_ms": round(latency, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "bundled scene scenes/%s (the reference's own input), camera resolution set to %dx%d"
-                                    % (args.scene, args.width, args.height),
-            "config": {"workload": "scenes/%s %dx%d, depth 5, %d point lights, frame = preprocess + grid build + trace + "
-                                   "shade + tone map%s" % (args.scene, args.width, args.height, scene.nl,
-                                                            " + RCCL min/max all-reduce + RGBA8 tile gather" if world > 1 else ""),
-                       "rays_per_frame": int(rays_frame), "tiling": "8x8 tiles round-robin over %d rank(s)" % world,
-                       "frames_in_flight": depth},
-            "kernel_ms_per_frame_rank0": dict({k: round(v / max(warm_frames, 1), 3) for k, v in tim_warm.items() if k.endswith("_ms")},
-                                              **{k: round(tim[k] / timed_frames, 3) for k in ("nearest_ms", "shadow_ms")}),
-            "kernel_ms_note": "HIP events on the stream each kernel runs on: nearest_ms and shadow_ms over the timed frames, the others "
-                              "over the warm-up frames (the events of every kernel cost 0.07 ms per frame); preprocess_ms and grid_ms are elapsed on the build "
-                              "stream, where the set-up of frame k+1 overlaps the walk kernels of frame k (alone it takes 0.27 ms)"
-                              + ("; with %d frames in flight a kernel shares the GPU with the other frame's, so these are longer than "
-                                 "the kernel alone" % depth if depth > 1 else ""),
-            "roofline": roof,
-        }
-        def ratio(a, b):
-            return round(a / b, 4) if b else None
-        out["walk_stats_rank0"] = {
+    ms_step = elapsed / steps * 1e3
+    fam = "shadow" if tim["shadow_ms"] >= tim["nearest_ms"] else "nearest"  # dominant kernel on this rank
+    launches = max(tim[fam + "_launches"], 1)
+    avg_ms = tim[fam + "_ms"] / launches
+    if fam == "shadow":
+        q, S, T = cnt["shadow_queries"], cnt["shadow_steps"], cnt["shadow_tests"]
+    else:
+        q, S, T = cnt["nearest_queries"], cnt["nearest_steps"], cnt["nearest_tests"]
+    per_launch = timed_frames / launches  # frames per launch of this family (1 when the frame is one chunk and one level)
+    full = cnt[fam + "_full_tests"]
+    workload = "%s %dx%d" % (scene_name, width, height)
+    roof = roofline(fam, avg_ms, q * per_launch, S * per_launch, T * per_launch, full * per_launch,
+                    cnt[fam + "_lane_slots"] * per_launch, workload if world == 1 else None)
+    roof["launches_per_frame"] = round(launches / max(timed_frames, 1), 2)
+
+    def ratio(a, b):
+        return round(a / b, 4) if b else None
+    return {
+        "value": round(rays_frame * steps / elapsed / 1e6, 3), "unit": "Mrays/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms_step, 3), "frame_latency_ms": round(latency, 3) if latency is not None else None,
+        "data": "bundled scene scenes/%s (the reference's own input), camera resolution set to %dx%d" % (scene_name, width, height),
+        "config": {"workload": "scenes/%s %dx%d, depth 5, %d point lights, frame = preprocess + grid build + trace + "
+                               "shade + tone map%s" % (scene_name, width, height, scene.nl,
+                                                        " + RCCL min/max all-reduce + RGBA8 tile gather" if world > 1 else ""),
+                   "rays_per_frame": int(rays_frame), "rays_per_pixel": round(rays_frame / (width * height), 2),
+                   "tiling": "8x8 tiles round-robin over %d rank(s)" % world,
+                   "frames_in_flight": depth, "chunks_per_frame_rank0": chunks["chunks"], "chunks_rerendered_rank0": chunks["chunks_rerendered"]},
+        "kernel_ms_per_frame_rank0": dict({k: round(v / max(warm_frames, 1), 3) for k, v in tim_warm.items() if k.endswith("_ms") and k not in ("preprocess_ms", "grid_ms")},
+                                          **{k: round(tim[k] / timed_frames, 3) for k in ("nearest_ms", "shadow_ms")}),
+        "setup_ms_on_build_stream_rank0": {k: round(tim_warm[k] / max(warm_frames, 1), 3) for k in ("preprocess_ms", "grid_ms")},
+        "roofline": roof,
+        "walk_stats_rank0": {
             f: {"simd_efficiency": ratio(cnt[f + "_lane_tests"], cnt[f + "_lane_slots"]),
                 "wave_tests": cnt[f + "_lane_slots"] // 64, "wave_cell_visits": cnt[f + "_visits"],
                 "batches_culled": ratio(cnt[f + "_batches_culled"], cnt[f + "_batches"]),
                 "reached_second_slabs": ratio(cnt[f + "_stage2"], cnt[f + "_lane_slots"] / 64),
                 "reached_distance_stage": ratio(cnt[f + "_stage3"], cnt[f + "_lane_slots"] / 64),
                 "reached_exact_test": ratio(cnt[f + "_exact"], cnt[f + "_lane_slots"] / 64)}
-            for f in ("nearest", "shadow")}
-        if world == 1 and not args.no_cpu_baseline:
+            for f in ("nearest", "shadow")},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="temple")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 1 on one GPU, 2 on several")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-width", type=int, default=960)
+    ap.add_argument("--cpu-height", type=int, default=540)
+    ap.add_argument("--no-config5", action="store_true", help="skip the scenes/ulica legs (1920x1080 and 7680x4320) of the result line")
+    args = ap.parse_args()
+
+    # Before anything touches torch or the GPU: a plain `python bench.py --gpus N` starts its own ranks.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%s but --gpus %d" % (os.environ["WORLD_SIZE"], args.gpus))
+
+    # Libraries below write banners to the C-level stdout (RCCL prints its version when a communicator is made); the
+    # one JSON line is the only thing this program may print there, so stdout points to stderr until that line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd.dist import default_depth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    force = world == 1 and os.environ.get("RTGPU_BENCH_FORCE_COLLECTIVES") == "1"  # rehearsal of the N > 1 code on one GPU
+    if world > 1 or force:
+        if force:
+            import socket
+            with socket.socket() as sk:  # a port that is free now
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            import raytracer_amd.dist as rdist
+            rdist.FORCE_COLLECTIVES = True
+        dist.init_process_group("nccl", device_id=dev)
+
+    env = {"torch": torch, "dist": dist, "rt": rt, "dev": dev, "rank": rank, "world": world, "local_rank": local_rank}
+    # Frames in flight on this rank's GPU (FramePipeline): one on a single GPU, two where a rank renders a share of the frame
+    depth = args.frames_in_flight if args.frames_in_flight > 0 else default_depth(world)
+    main_leg = run_leg(env, args.scene, args.width, args.height, args.steps, args.warmup, depth)
+    # Config 5 of the baseline (scenes/ulica at 7680x4320, maximum depth: the divergence stress) beside the headline
+    # workload, with its own rooflines: 1920x1080 (three frames) and the full 7680x4320 (one frame), same ranks, same exchange.
+    legs = {}
+    if not args.no_config5 and args.scene == "temple":
+        for name, w, h, k, wu, reps in (("ulica_1920x1080", 1920, 1080, 3, 1, 1), ("ulica_7680x4320", 7680, 4320, 1, 1, 0)):
             try:
-                out["cpu_baseline"] = cpu_baseline(prefix, over, args.cpu_width, args.cpu_height)
+                legs[name] = run_leg(env, "ulica", w, h, k, wu, depth, reps)
+            except Exception as e:  # an extra of the line: never a reason to lose the headline number
+                legs[name] = {"error": str(e)}
+
+    if rank == 0:
+        out = {"metric": "Mrays/s (primary+secondary)", "value": main_leg["value"], "unit": "Mrays/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"],
+               "frame_latency_ms": main_leg["frame_latency_ms"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": main_leg["data"], "config": main_leg["config"],
+               "kernel_ms_per_frame_rank0": main_leg["kernel_ms_per_frame_rank0"],
+               "setup_ms_on_build_stream_rank0": main_leg["setup_ms_on_build_stream_rank0"],
+               "kernel_ms_note": "HIP events on the stream each kernel runs on: nearest_ms and shadow_ms over the timed frames, the others "
+                                 "over the warm-up frames (the events of every kernel cost 0.07 ms per frame); kernel_ms_per_frame_rank0 sums to the frame. "
+                                 "setup_ms_on_build_stream_rank0 is the set-up of frame k+1 (preprocess, grid build: 0.27 ms alone) as it elapses on the build "
+                                 "stream UNDER the walk kernels of frame k, where it waits for free compute units: not part of the frame's critical path"
+                                 + ("; with %d frames in flight a kernel shares the GPU with the other frame's, so these are longer than "
+                                    "the kernel alone" % depth if depth > 1 else ""),
+               "roofline": main_leg["roofline"], "walk_stats_rank0": main_leg["walk_stats_rank0"]}
+        if legs:
+            out["config5"] = legs
+        if world == 1 and not args.no_cpu_baseline:
+            prefix, over = SCENES[args.scene]
+            try:
+                out["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, prefix), over, args.cpu_width, args.cpu_height)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": str(e)}
+            if legs:  # config 5's baseline: the same scene at 160x90 (the reference needs 20 core-hours for a 7680x4320 frame)
+                try:
+                    out["config5"]["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, SCENES["ulica"][0]), {}, 160, 90)
+                except Exception as e:
+                    out["config5"]["cpu_baseline"] = {"error": str(e)}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

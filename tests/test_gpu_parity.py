@@ -1,6 +1,7 @@
 """Parity of the HIP trace path (through the C ABI of librtgpu.so) with the reference.
 
-Bars: primary-hit triangle ids bit-exact; 8-bit RGB within 1/255 per channel.
+Bars: primary-hit triangle ids bit-exact; 8-bit RGB within 1/255 per channel (asserted here at what is observed on the
+golden cases: raw colours bit-identical to the cache-less oracle, identical bytes).
 Checked three ways:
   * against the committed golden dumps of the unmodified reference (tests/golden/*.npz),
   * against the CPU oracle on the same inputs (grid lists, per-triangle preprocess, raw float colour),
@@ -83,13 +84,14 @@ def test_frame_matches_reference_golden(renderer, name):
     exact = (g["rgb"].view(np.uint32) == o["rgb"].view(np.uint32)).all(-1)[clean].mean()
     print("%s: raw colour bit-exact on %.4f of pixels, max rel diff %.3g" % (name, exact, rel.max() if rel.size else 0))
     assert np.isfinite(g["rgb"][clean]).all() == np.isfinite(o["rgb"][clean]).all()
-    assert rel.max() < 1e-4  # only pow() (ocml vs glibc) may differ, by an ulp of the double result
-    # ... and where no pow() is involved (ks = 0: all of temple and test, parts of the others) every bit is the oracle's
+    # where no pow() is involved (ks = 0: all of temple and test, parts of the others) every bit is the oracle's by construction
     nopow = pow_free_pixels(scene, g["ids"]) & clean
     assert (g["rgb"].view(np.uint32) == o["rgb"].view(np.uint32))[nopow].all(), "a colour without pow() differs from the oracle"
     if name in ("temple", "test"):
-        assert nopow.all() and exact == 1.0
-    assert exact >= 0.999  # observed: 1.0 on every case (the double results of the two pow() round to the same float)
+        assert nopow.all()
+    # ... and with pow() (the GPU's math library against glibc's: the double results could differ in their last place) every
+    # pixel of every case has been bit-identical so far: the bar is what is observed, so that a regression cannot hide below it
+    assert exact == 1.0 and (rel.size == 0 or rel.max() == 0.0)
     # 3. the 8-bit image against the reference's: within 1/255 per channel
     if tex:
         mm = o["minmax"]  # the reference's own min/max is polluted by its uninitialised samples; share one
@@ -101,7 +103,7 @@ def test_frame_matches_reference_golden(renderer, name):
     img = rgba_to_u8(renderer.tonemap_host(g["rgb"], mm, scene.gamma)).astype(int)
     d8 = np.abs(img - ref_img)[clean]
     print("%s: 8-bit max diff %d, pixels off by one %d of %d" % (name, d8.max(), int((d8 > 0).any(-1).sum()), d8.shape[0]))
-    assert d8.max() <= 1
+    assert d8.max() == 0  # (the bar of the port is 1/255 per channel; observed on these cases: identical bytes)
 
 
 @pytest.mark.parametrize("name", ["test", "s2", "s3", "s5", "pokoj", "temple", "ulica"])

@@ -105,3 +105,75 @@ def test_oracle_matches_live_reference_at_odd_resolution():
     o = O.OracleScene(prefix, width=97, height=61).render(shadow_cache=True)
     assert np.array_equal(o["ids"], ref["ids"])
     assert np.array_equal(o["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["pokoj_cegly", "pokoj_kafelki"])
+def test_tainted_pixels_are_the_ones_the_references_condition_names(name):
+    """Where the reference reads texture samples it never wrote (raytrace.c:90-105 leaves cx1 / cx2 / cy1 / cy2 as they
+    were when px -+ 0.002 or py -+ 0.002 leaves [0, 1], and raytrace.c:119-120 reads them) its colours are not
+    comparable; the oracle marks those pixels (`taint`).  Which pixels those are is restated here from the reference's
+    lines alone, in numpy, for the primary hits: the pixel's ray (vectormath.h:108-118), the hit's barycentrics
+    (intersection.c:62-76), the texture coordinates of the four textured triangles (preprocess.c:45-71, raytrace.c:81-82)
+    and the condition itself.  Every pixel the restatement names is tainted; a tainted pixel it does not name got its
+    taint from a secondary ray, so its primary hit lies on a surface that spawns one (kr > 0 or kt > 0); and every pixel
+    in which the reference's colours differ from the oracle's is tainted."""
+    import raytracer_amd as rt
+    F = np.float32
+    z, prefix, over = load_case(name)
+    h, w = z["ids"].shape
+    cwd = os.getcwd()
+    os.chdir(ROOT)  # textures/brickwall.bmp, the reference's texture switch, is looked up in the working directory
+    try:
+        scene = rt.Scene(prefix, texture=True, width=w, height=h, **over)
+        o = O.OracleScene(prefix, texture=True, width=w, height=h, **over).render(shadow_cache=True)
+    finally:
+        os.chdir(cwd)
+    ids, taint = o["ids"], o["taint"].astype(bool)
+    verts, sid = scene.vertices().astype(F), scene.sids()
+    seven = np.flatnonzero(sid == 7)
+    tex = {int(seven[0]): ((0, 1), (1, 0), (0, 0)), int(seven[1]): ((0, 1), (1, 1), (1, 0)),
+           int(seven[6]): ((0, 1), (0.8, 0), (0, 0)), int(seven[7]): ((0, 1), (0.8, 1), (0.8, 0))}  # ti, tj, tk
+    cam = scene.camera
+    ob, ul, bl, ur = (np.array(v[:], F) for v in (cam.ob, cam.ul, cam.bl, cam.ur))
+    ys, xs = np.mgrid[0:h, 0:w]
+    xc, yc = xs.astype(F) * (F(1.0) / F(w)), ys.astype(F) * (F(1.0) / F(h))
+    d = [(xc * (ur[k] - ul[k]) + yc * (bl[k] - ul[k]) + ul[k] - ob[k]).astype(F) for k in range(3)]
+    ss = ((d[0] * d[0] + d[1] * d[1]).astype(F) + d[2] * d[2]).astype(F)
+    inv = (1.0 / np.sqrt(ss.astype(np.float64))).astype(F)
+    r = [(c * inv).astype(F) for c in d]
+
+    def cross(a, b):
+        return [(a[1] * b[2] - a[2] * b[1]).astype(F), (a[2] * b[0] - a[0] * b[2]).astype(F), (a[0] * b[1] - a[1] * b[0]).astype(F)]
+
+    def dot(a, b):
+        return ((a[0] * b[0] + a[1] * b[1]).astype(F) + a[2] * b[2]).astype(F)
+
+    named = np.zeros((h, w), bool)
+    for t, (ti, tj, tk) in tex.items():
+        m = ids == t
+        if not m.any():
+            continue
+        i, ij, ik = verts[t, 0:3], (verts[t, 3:6] - verts[t, 0:3]).astype(F), (verts[t, 6:9] - verts[t, 0:3]).astype(F)
+        rr = [c[m] for c in r]
+        pvec = cross(rr, [F(x) for x in ik])
+        det = dot([F(x) for x in ij], pvec)
+        inv_det = (F(1.0) / det).astype(F)
+        tvec = [F(ob[k] - i[k]) for k in range(3)]
+        u = (dot(tvec, pvec) * inv_det).astype(F)
+        qvec = cross(tvec, [F(x) for x in ij])
+        v = (dot(rr, qvec) * inv_det).astype(F)
+        px = ((F(ti[0]) + (F(tj[0]) - F(ti[0])) * u).astype(F) + (F(tk[0]) - F(ti[0])) * v).astype(F)
+        py = ((F(ti[1]) + (F(tj[1]) - F(ti[1])) * u).astype(F) + (F(tk[1]) - F(ti[1])) * v).astype(F)
+        dl = F(0.002)
+        bad = ~((px - dl).astype(F) >= 0) | ~((px + dl).astype(F) <= 1) | ~((py - dl).astype(F) >= 0) | ~((py + dl).astype(F) <= 1)
+        named[m] = bad
+    assert named.sum() > 0
+    assert taint[named].all(), "a pixel the reference's condition names is not marked"
+    surf = scene.desc.surfaces
+    spawns = np.array([surf[k].kr > 0 or surf[k].kt > 0 for k in range(scene.ns)])
+    rest = taint & ~named
+    assert (ids[rest] >= 0).all() and spawns[sid[ids[rest]]].all(), "a pixel is marked that neither the condition names nor a secondary ray can reach"
+    differs = ~(o["rgb"].view(np.uint32) == z["rgb"].view(np.uint32)).all(-1)
+    assert taint[differs].all()
+    print("%s: %d pixels named by the condition, %d more tainted through secondary rays, %d differ from the reference's run"
+          % (name, int(named.sum()), int(rest.sum()), int(differs.sum())))

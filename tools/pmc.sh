@@ -10,7 +10,8 @@ P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE
 P3="SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_IFETCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_SMEM SQ_INSTS_VALU_TRANS_F32 SQ_CYCLES"
 i=1
 for P in "$P1" "$P2" "$P3"; do
-  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $ROOT/gpurun_out/pmc_${TAG}_$i -- python3 $ROOT/tools/kbench.py --one $SCENE $W $H > $ROOT/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $ROOT/gpurun_out/pmc_${TAG}_$i.log; exit 1; }
+  rm -rf $ROOT/gpurun_out/pmc_${TAG}_$i
+  timeout -s KILL 180 rocprofv3 --pmc $P --output-format csv -d $ROOT/gpurun_out/pmc_${TAG}_$i -- python3 $ROOT/tools/kbench.py --one $SCENE $W $H > $ROOT/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $ROOT/gpurun_out/pmc_${TAG}_$i.log; exit 1; }
   i=$((i+1))
 done
 echo done $TAG

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc CSV output: per kernel, mean of each counter over its dispatches.
-usage: tools/pmc_summary.py [--workload "temple 3840x2160"] gpurun_out/pmc_<tag>_*
-Also writes profiles/pmc.json: the means, machine-readable, stamped with the workload and with the SHA-256 of the
-kernel sources they were collected on (bench.py ignores the file when that differs from its own tree's)."""
+usage: tools/pmc_summary.py [--workload "temple 3840x2160"] [--out pmc.json] gpurun_out/pmc_<tag>_*
+Also writes profiles/<out> (default pmc.json): the means, machine-readable, stamped with the workload and with the SHA-256
+of the kernel sources they were collected on (bench.py picks the file by its workload and ignores it when the sources
+differ from its own tree's)."""
 import csv
 import json
 import glob
@@ -16,8 +17,13 @@ from raytracer_amd.api import csrc_hash  # noqa: E402
 
 argv = sys.argv[1:]
 workload = "temple 3840x2160"
-if argv and argv[0] == "--workload":
-    workload, argv = argv[1], argv[2:]
+out_name = "pmc.json"
+while argv and argv[0] in ("--workload", "--out"):
+    if argv[0] == "--workload":
+        workload = argv[1]
+    else:
+        out_name = argv[1]
+    argv = argv[2:]
 acc = defaultdict(lambda: defaultdict(list))
 for d in argv:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -39,4 +45,4 @@ for k in acc:
             out[fam.split("<")[0]] = {c: sum(v) / len(v) for c, v in acc[k].items()}
 if out:
     json.dump({"method": "rocprofv3 --pmc, means over the launches of one run of tools/kbench.py --one", "workload": workload,
-               "csrc_sha256": csrc_hash(), **out}, open(os.path.join(ROOT, "profiles", "pmc.json"), "w"), indent=1)
+               "csrc_sha256": csrc_hash(), **out}, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1)

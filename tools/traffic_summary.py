@@ -12,6 +12,7 @@ import sys
 from collections import defaultdict
 
 root, scene, w, h = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+out_name = sys.argv[5] if len(sys.argv) > 5 else "traffic.json"  # file under profiles/ (bench.py picks it by its workload)
 sys.path.insert(0, os.path.dirname(os.path.abspath(root)))
 from raytracer_amd.api import csrc_hash  # noqa: E402
 acc = defaultdict(lambda: defaultdict(list))
@@ -28,5 +29,5 @@ for k in ("k_nearest", "k_shadow", "k_hit", "k_accumulate"):
     hit, miss = m.get("TCC_HIT_sum", 0.0), m.get("TCC_MISS_sum", 0.0)
     out[k] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
               "l2_hit_rate": hit / (hit + miss) if hit + miss else None, "l2_requests_per_launch": hit + miss, "launches_averaged": len(next(iter(acc[k].values())))}
-json.dump(out, open(os.path.join(os.path.dirname(root), "profiles", "traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(root), "profiles", out_name), "w"), indent=1)
 print(json.dumps(out, indent=1))
