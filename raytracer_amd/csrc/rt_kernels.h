@@ -20,6 +20,9 @@
 // the light (the kernels built with ENDS) it pays (ulica 1080p 116.5 against 118.9 ms without).
 #define RT_SHADOW_RAYCULL(RECTEST, ENDS) ((ENDS) || !(RECTEST))
 #endif
+#ifndef RT_FLAT
+#define RT_FLAT 64  // lists of up to this many records are culled record by record, 64 at a time, without the batch level (stream_cell; 0: never)
+#endif
 #ifndef RT_WAVES_ACC
 #define RT_WAVES_ACC 4  // k_accumulate: 128 instead of 131 registers buy a fourth wave per SIMD (0.27 -> 0.23 ms); five spill (0.51 ms)
 #endif
@@ -164,8 +167,13 @@ RT_D Fan make_fan(bool in, f3 a, f3 L, float smax) {
   f.lnorm = lane_bcast(__builtin_fabsf(L.x) + __builtin_fabsf(L.y) + __builtin_fabsf(L.z), 0);
   return f;
 }
-template <bool ENDS>
-RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, float tmax, float tend, int leader) {
+// TICKET: onorm_all, tmax_all are wave-uniform upper bounds of |o| and of the range's end over ALL the ticket's rays, worked
+// out once per ticket (they enter margins and the opaque range test only); else they are worked out here, for the group.
+// one_end: every ray of the ticket ends at the same point (the shadow rays of one point light): the end points o + tend r
+// differ from it by rounding only.
+template <bool ENDS, bool TICKET = false>
+RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, float tmax, float tend, int leader,
+                        float onorm_all = -1.0f, float tmax_all = -1.0f, bool one_end = false) {
   Bundle b;
   b.axis = lane_bcast3(r, leader);
   b.m = lane_bcast3(pm, leader);
@@ -174,25 +182,36 @@ RT_D Bundle make_bundle(bool in, f3 o, f3 r, f3 pm, float odr, float onorm, floa
   // a NaN would be dropped by the max: it becomes +inf (nothing is culled for a group with such a ray)
   float rho = in ? __builtin_amdgcn_sqrtf(dot3(dr, dr)) * 1.001f + 1e-7f : 0.0f;
   float ro = in ? __builtin_amdgcn_sqrtf(dot3(dorg, dorg)) * 1.001f : 0.0f;
-  float on = in ? onorm : 0.0f;
-  float tm = in ? tmax : -INFINITY;
   if (!(rho >= 0.0f)) rho = INFINITY;
   if (!(ro >= 0.0f)) ro = INFINITY;
-  if (!(on >= 0.0f)) on = INFINITY;
-  if (tm != tm) tm = INFINITY;
   b.rho = wave_max(rho);
   b.ro = wave_max(ro);
-  b.onorm = wave_max(on);
-  b.tmax = wave_max(tm);
+  if (TICKET) {
+    b.onorm = onorm_all;
+    b.tmax = tmax_all;
+  } else {
+    float on = in ? onorm : 0.0f;
+    float tm = in ? tmax : -INFINITY;
+    if (!(on >= 0.0f)) on = INFINITY;
+    if (tm != tm) tm = INFINITY;
+    b.onorm = wave_max(on);
+    b.tmax = wave_max(tm);
+  }
   b.re = INFINITY; b.T = INFINITY;
   b.fan = no_fan();
   if (ENDS) {  // (a walk kernel's rays all end, or none does; decided at compile time, the bundle's numbers stay in scalar registers)
     // end points in float: off the line's own point at tend by at most 3 eps (|o| + tend), covered by 2e-6 (onorm + tend)
-    const f3 e = mk3(__builtin_fmaf(tend, r.x, o.x), __builtin_fmaf(tend, r.y, o.y), __builtin_fmaf(tend, r.z, o.z));
-    const f3 de = sub3(e, lane_bcast3(e, leader));
-    float re = in ? __builtin_fmaf(__builtin_amdgcn_sqrtf(dot3(de, de)), 1.001f, 2e-6f * (onorm + tend)) : 0.0f;
-    if (!(re >= 0.0f)) re = INFINITY;
-    b.re = wave_max(re);
+    float re_all;
+    if (TICKET && one_end) {
+      re_all = 2e-6f * (b.onorm + b.tmax);  // (tend <= tmax_all: the rays' ranges end where they meet)
+    } else {
+      const f3 e = mk3(__builtin_fmaf(tend, r.x, o.x), __builtin_fmaf(tend, r.y, o.y), __builtin_fmaf(tend, r.z, o.z));
+      const f3 de = sub3(e, lane_bcast3(e, leader));
+      float re = in ? __builtin_fmaf(__builtin_amdgcn_sqrtf(dot3(de, de)), 1.001f, 2e-6f * (onorm + tend)) : 0.0f;
+      if (!(re >= 0.0f)) re = INFINITY;
+      re_all = wave_max(re);
+    }
+    b.re = lane_bcast(re_all, 0);  // (a wave-uniform value that vector arithmetic produced: back into a scalar register)
     b.T = lane_bcast(tend, leader);
   }
   return b;
@@ -519,6 +538,7 @@ RT_D bool fan_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float k1max, 
 // staging; without it every record of a kept batch is tested.  It pays where bundles are narrow against the triangles.
 // ENDS: the bundle's rays end (Bundle.re, .T are set) and the bundle test uses that.
 // RAYCULL: with the ray-by-ray test of the candidates' boxes (cull).
+constexpr int kSliceFloatsC = kHdrChunk * kHdrFloats + 2 * kBatch * kRecFloats;  // LDS floats per wavefront (kSliceFloats)
 template <bool RECTEST, bool ENDS, bool RAYCULL, typename C, typename T, typename B, typename P, typename F, typename G>
 RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt, float *slice, int lane, const Bundle &bundle_,
                       bool transparent_counts_anywhere, Phases &ph, C &&cull, T &&tally, B &&batch,
@@ -530,6 +550,78 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
   const TriRec *__restrict__ recs = g.cell_tris;
   const float4 *hsrc = reinterpret_cast<const float4 *>(g.cell_hdrs + hbeg);
   const uint32_t nb = (cnt + kBatch - 1) / kBatch;
+#if RT_FLAT
+  // Short lists (up to RT_FLAT records: nine of ten cell visits in a scene of many small cells) without the batch level:
+  // 64 records at a time, one lane per record reads its record from memory and asks whether any ray of the bundle can
+  // pass its three slabs (bundle_slabs_pass, with the distance bound and the lines' spread box_test_bundle works out for
+  // the record's batch); the records that are left go to LDS in list order and are tested there.  One memory round trip
+  // and one pass of the wavefront instead of header staging, grazing bound, two box tests and the record-level pass.
+  if (RECTEST && ENDS && cnt <= (uint32_t)RT_FLAT) {  // (in the walks whose rays start on one tile short lists are rare, and the pass costs their kernels registers)
+    Bundle bundle = bundle_;
+    asm volatile("" : "+s"(bundle.axis.x), "+s"(bundle.axis.y), "+s"(bundle.axis.z), "+s"(bundle.rho), "+s"(bundle.ro), "+s"(bundle.onorm));
+    for (uint32_t p0 = 0; p0 < cnt; p0 += 64u) {
+      const uint32_t at = p0 + (uint32_t)lane;
+      bool pass = false;
+      const v4f *R = reinterpret_cast<const v4f *>(recs + beg + at);
+      if (at < cnt) {
+        const v4f hc = *reinterpret_cast<const v4f *>(g.cell_hdrs + hbeg + (at >> 3));  // the batch's box centre and radius
+        const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+        RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
+        const f3 ab = mk3(r3.x, r3.y, r3.z), pv = mk3(r3.w, r4.x, r4.y);
+        // tv >= |o - v| for every origin o of the bundle and every vertex v of the batch, and the spread of the bundle's lines
+        // there: the expressions of box_test_bundle
+        const BoxRay b = box_ray(mk3(hc.x, hc.y, hc.z), bundle.axis, bundle.m, bundle.odr);
+        const float d2 = __builtin_fmaf(b.ex, b.ex, __builtin_fmaf(b.ey, b.ey, b.ez * b.ez));
+        const float on5 = 0.00001f * bundle.onorm;
+        float tv = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(b.tc, b.tc, d2)), 1.001f, on5 + hc.w);
+        tv = __builtin_fmaf(bundle.ro, 1.001f, tv);
+        float spread = __builtin_fmaf(tv, bundle.rho, 1.000001f * bundle.ro);
+        if (ENDS) {
+          const float te = bundle.T - b.tc;
+          const float tb = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(te, te, d2)), 1.001f, on5 + hc.w);
+          spread = __builtin_fminf(spread, __builtin_fmaf(tb, bundle.rho, 1.000001f * bundle.re));
+        }
+        const float kc_max = __builtin_fmaf(r0.w, bundle.onorm, r2.w) + g.slack;  // the record's own k1, k2
+        pass = bundle_slabs_pass(A, ab, pv, kc_max, spread, bundle);
+      }
+      const unsigned long long left = __ballot(pass);
+      {
+        const uint32_t nbp = (cnt - p0 < 64u ? cnt - p0 + kBatch - 1 : 64u) / kBatch;
+        int culled = 0;
+        for (uint32_t b = 0; b < nbp; b++) culled += ((left >> (8u * b)) & 0xffull) == 0ull ? 1 : 0;
+        tally((int)nbp, culled);
+      }
+      ph.template end<3>();
+      // up to 48 records fit the wavefront's slice; more (rare) go in a second round
+      constexpr int kFlatSlots = kSliceFloatsC / kRecFloats;
+      unsigned long long todo = left;
+      while (todo != 0) {
+        const int before = __popcll(todo & lanes_below(lane));
+        const bool mine = ((todo >> lane) & 1ull) != 0 && before < kFlatSlots;
+        if (mine) {  // (read again, from the vector cache, rather than held in twenty registers through the pass)
+          v4f *D = reinterpret_cast<v4f *>(slice + before * kRecFloats);
+          const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+          D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4;
+        }
+        const unsigned long long placed = __ballot(mine);
+        todo &= ~placed;
+        __builtin_amdgcn_wave_barrier();
+        const int n = __popcll(placed);
+        tally(-2, n);
+        ph.template end<4, true>();
+        for (int j = 0; j < n; j++) {
+          const float *Rj = slice + j * kRecFloats;
+          batch(Rj[3], Rj[11]);
+          f(Rj, 0u, true);
+          if (!more()) { ph.template end<5>(); return; }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      ph.template end<5>();
+    }
+    return;
+  }
+#endif
   for (uint32_t h0 = 0; h0 < nb; h0 += kHdrChunk) {
     // The bundle's numbers are wave-uniform and live in scalar registers; their products with constants (axis / 511,
     // 1e-5 onorm, ...) are vector arithmetic, and hoisted out of this loop each holds a vector register for the whole
@@ -711,7 +803,7 @@ RT_D void stream_cell(const GridP &g, uint32_t hbeg, uint32_t beg, uint32_t cnt,
     ph.template end<5>();
   }
 }
-constexpr int kSliceFloats = kHdrChunk * kHdrFloats + 2 * kBatch * kRecFloats;  // LDS floats per wavefront
+constexpr int kSliceFloats = kSliceFloatsC;
 
 RT_D int rec_id(const float *R) { return __float_as_int(R[10]); }
 // The exact test of a triangle the filter could not decide: i, ij, ik by index.
@@ -770,7 +862,7 @@ RT_D int shadow_verdict(const float *R, const RecA &A, PlTest &t, f3 o, f3 r, f3
 #define RT_CELL_MIN_GROUP 32  // rays sharing the leader's cell from which cell mode is taken unconditionally
 #endif
 #ifndef RT_SHORT_LIST
-#define RT_SHORT_LIST 32      // lists up to this length are walked in lane mode
+#define RT_SHORT_LIST 12      // lists up to this length are walked in lane mode (32: ulica's shadow walks 2 % slower; temple the same)
 #endif
 #ifndef RT_LANE_MIN
 #define RT_LANE_MIN 8         // lane mode needs at least this many rays with short lists
@@ -2002,6 +2094,20 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
     // points, in the kernels built without ENDS, i.e. for scenes without secondary rays: with the fan compiled into ulica's
     // kernel its shadow walks took 114 instead of 107 ms, whichever tickets used it).  Built once per ticket, from all its
     // walks: the groups of its cell visits are nearly the whole ticket.
+    // Bounds over all the ticket's walks, once per ticket (make_bundle): |a|, the rays' lengths, and whether they all end at
+    // one point light.
+    float onorm_all = -1.0f, tmax_all = -1.0f;
+    bool one_end = false;
+    if (ENDS) {
+      float on = alive ? onorm : 0.0f, tm = alive ? dmax : 0.0f;
+      if (!(on >= 0.0f)) on = INFINITY;
+      if (!(tm >= 0.0f)) tm = INFINITY;
+      onorm_all = wave_max(on);
+      tmax_all = wave_max(tm);
+      const unsigned long long walking = __ballot(alive);
+      const int slot_first = __builtin_amdgcn_readlane(slot, walking != 0 ? __ffsll(walking) - 1 : 0);
+      one_end = slot_first < fresh_arg<ShadeP>(offsetof(ShadowArgs, sp)).nl && __ballot(alive && slot != slot_first) == 0;
+    }
     Fan ticket_fan = no_fan();
     if (RECTEST && !ENDS && order == nullptr) {
       const unsigned long long walking = __ballot(alive);
@@ -2064,7 +2170,8 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
         // lanes outside the cell, and blocked ones, test with kc = -inf: rejected by the first slab
         float kc = -INFINITY;
         bool go = __ballot(in_group) != 0;  // some ray of the group is still unblocked
-        Bundle bundle = make_bundle<ENDS>(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader));
+        Bundle bundle = make_bundle<ENDS, ENDS>(in_group, a, r, pm, odr, onorm, dmax, ENDS ? dmax : INFINITY, central_lane(in_group, lane, order == nullptr, leader),
+                                                onorm_all, tmax_all, one_end);
         bundle.fan = ticket_fan;
         if (go)
           stream_cell<RECTEST, ENDS, RT_SHADOW_RAYCULL(RECTEST, ENDS)>(g, hbeg, beg, cnt, slice, lane, bundle, true, ph,

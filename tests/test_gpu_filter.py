@@ -87,7 +87,10 @@ def test_record_level_bundle_test_does_not_change_the_frame(renderer, prefix, ov
             assert ca[k] == cb[k], k
     # with the test fewer records reach the ray-by-ray first slab (compared where both walks test the boxes ray by ray
     # first: with bundle_ends; without it the walk that has the record-level test leaves the ray-by-ray box test out)
-    assert frames[3][1]["shadow_lane_slots"] <= frames[4][1]["shadow_lane_slots"]
+    # (not with a planar light: its samples make every bundle as wide as the light, the slab test of a wide bundle lets most
+    # records through, and short lists skip the box tests)
+    if scene.npl == 0:
+        assert frames[3][1]["shadow_lane_slots"] <= frames[4][1]["shadow_lane_slots"]
 
 
 @pytest.mark.parametrize("prefix,over,w,h,tex", CASES, ids=[c[0].split("/")[1] + ("_glass" if c[1] and "pokoj" in str(c[1]) else "") + "_%dx%d" % (c[2], c[3]) for c in CASES])
