@@ -123,6 +123,12 @@ RT_D int least_advanced(unsigned long long m, bool alive, float tx, float ty, fl
 // Otherwise the rays come in queue order (secondary rays, nodes ordered by the cell of their hit point), in which
 // neighbours lie close together: the lane of the group nearest the middle of the wavefront.
 RT_D int central_lane(bool in, int lane, bool tile, int fallback) {
+  if (!tile) {  // (wave-uniform) the set bit of the group's mask nearest the middle, of two equally near the lower: scalar bit arithmetic
+    const unsigned long long m = __ballot(in);
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const int below = lo != 0u ? 31 - __clz((int)lo) : -1000, above = hi != 0u ? 31 + __ffs((int)hi) : 1000;
+    return m == 0ull ? fallback : (63 - 2 * below <= 2 * above - 63 ? below : above);
+  }
   asm volatile("" : "+v"(lane));  // (the key is worked out per visit: as a loop invariant it would be spilled and reloaded)
   const int x2 = 2 * (lane & 7) - 7, y2 = 2 * (lane >> 3) - 7, l2 = 2 * lane - 63;
   const int off = tile ? x2 * x2 + y2 * y2 : (l2 < 0 ? -l2 : l2);
