@@ -1,14 +1,26 @@
-import os, sys, json
-sys.path.insert(0, os.getcwd())
-import raytracer_amd as rt
-sc = rt.Scene("scenes/ulica/ulica", width=1920, height=1080)
-for opts in ({}, {"order": 2}, {"order": 2, "order_parts": 4}, {"record_test": 0}, {"bundle_ends": 0}):
+#!/usr/bin/env python3
+"""Per-kernel device time of one frame under several option settings, each in a fresh context.
+usage: tools/opt_ab.py scene w h 'opt=val,opt=val' ['...' ...]     ('' = the defaults)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import raytracer_amd as rt  # noqa: E402
+from tools.diag import SCENES  # noqa: E402
+
+scene, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+sc = rt.Scene(os.path.join(ROOT, SCENES[scene]), width=w, height=h)
+for spec in sys.argv[4:] or [""]:
+    opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in spec.split(",") if kv)
     r = rt.Renderer(0, timing=1)
-    for k, v in opts.items(): r.set_option(k, v)
+    for k, v in opts.items():
+        r.set_option(k, v)
     r.upload(sc)
     best = None
-    for _ in range(3):
+    for _ in range(5):
         r.frame_begin(); r.render_host(); t = r.timings().asdict()
-        if best is None or t["shadow_ms"] < best["shadow_ms"]: best = t
-    print(opts, {k: round(v, 2) for k, v in best.items() if k in ("nearest_ms", "shadow_ms", "hit_ms", "accumulate_ms")}, flush=True)
+        if best is None or t["shadow_ms"] + t["nearest_ms"] < best["shadow_ms"] + best["nearest_ms"]:
+            best = t
+    print(spec or "defaults", {k: round(v, 3) for k, v in best.items() if k.endswith("_ms")}, flush=True)
     r.close()
