@@ -114,6 +114,9 @@ typedef struct rtgpu_counters {
   /* Chunks of tiles the last rtgpu_render call cut this rank's share into, and how many of them it rendered a second
    * time because a queue of secondary rays, sized from earlier chunks, was too small (option "queue_sizing"). */
   int64_t chunks, chunks_rerendered;
+  /* Shadow tickets (64 shadow queries of one light) answered from the light's lists, and tickets the lists were tried
+   * for but which took the walk after all (option "light_lists"; counted without "count" too). */
+  int64_t shadow_list_tickets, shadow_list_fallbacks;
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP
@@ -273,6 +276,24 @@ int rtgpu_ticket_log(rtgpu_ctx *ctx, int which, uint32_t *out, int max_tickets, 
  * forms on the device for all 2^32 float inputs and returns the number of inputs whose results differ
  * (mismatches[0]: reciprocal square root, mismatches[1]: square root).  Both must be 0.  About 0.1 s. */
 int rtgpu_math_selfcheck(rtgpu_ctx *ctx, uint64_t mismatches[2]);
+
+/* Diagnostics of the light lists, no counterpart in the reference, host code only (no GPU needed).  In a scene without
+ * transparent triangles the shadow queries towards a point light are answered from a table around the light (option
+ * "light_lists"): the faces of a cube around the light cut into texels, each listing the triangles the reference's test
+ * (src/intersection.c:58-86) can accept for a shadow ray (src/raytrace.c:206-216, src/voxelize.c:615-738) seen from the
+ * light in that texel.  These two calls return what the table is filled from, so that its completeness can be checked
+ * against the test itself.
+ * rtgpu_light_list_pairs: for n (triangle, light) pairs (verts n x 9: i, j, k; lights n x 3) and rays whose origin
+ * has a norm of at most olim, out[n][6][5] = per cube face (+x, -x, +y, -y, +z, -z) found (0 / 1) and the rectangle
+ * u0, u1, v0, v1 in face coordinates (the two other axes in ascending order, divided by the dominant one's magnitude).
+ * rtgpu_light_list_rects: the whole table for a scene as the library would build it with R x R texels per face
+ * (olim <= 0: chosen from the scene): faces[nl * 6][8] = p0, q0, sp, sq, p1, q1, base, on (the last two as uint32
+ * bits): the window of the face and the scale of its texels; rects[*n_rects][3] = face index (light * 6 + face), packed
+ * texel rectangle (columns a0 | a1 << 8, rows b0 << 16 | b1 << 24), triangle.  cap: room in rects (in rectangles);
+ * *n_rects is the number there would be.  *refs: the sum of the rectangles' areas. */
+int rtgpu_light_list_pairs(int64_t n, const float *verts, const float *lights, float olim, double *out);
+int rtgpu_light_list_rects(int32_t nt, const float *verts, int32_t nl, const float *lights, int32_t R, float olim, int64_t cap,
+                           uint32_t *rects, float *faces, float *olim_out, int64_t *n_rects, int64_t *refs);
 
 /* Single-GPU convenience for a C host: frame_begin must have been called; renders all tiles and
  * returns row-major host arrays (rgb w*h*3, ids w*h, minmax 6).  Any output may be NULL. */

@@ -530,6 +530,23 @@ RT_D bool fan_slabs_pass(const RecA &A, f3 ab, f3 P, float kc_max, float k1max, 
   return !((__builtin_fabsf(x1) - s1 > T) | (__builtin_fabsf(x2) - s2 > T) | (__builtin_fabsf(x3) - s3 > T));
 }
 
+// Does the triangle's plane lie behind every ray of the fan (no ray can reach it: tri_test's d is negative)?  true only
+// if surely so.  With dp* = i.N - o.N and det* = r.N (rt_math.h) d = dp* / det*, and tri_test accepts only if its own d is
+// not negative, which with its rounding (|dp - dp*| <= 10.5 eps L^2 (|o| + A), |det - det*| <= 8.9 eps L^2) means
+// sign(det*) dp* >= -10.5 eps L^2 (|o| + A) once |det*| > 8.9 eps L^2.  For the fan's ray from a: s det* = (L - a).N up to
+// 4 eps L^2 s, and dp* = an - a.N, both affine in a with gradient -N: over the box c +- h they stay within over_box(N) of
+// their values at c.  So no ray of the fan is accepted if |det(c)| - over_box(N) > 1.5 kc_max smax (the sign is the same for
+// all of them and det* is large enough) and sign(det(c)) dp(c) + over_box(N) < -2 |ac| kc_max (|ac| the longest edge; kc >=
+// 144 eps L (|o| + A) + 56 eps L^2 leaves more than ten times the rounding of either side, binary32 evaluation included).
+RT_D bool fan_plane_behind(const RecA &A, float an, float kc_max, const Fan &f) {
+  const float det = __builtin_fmaf(f.rc.x, A.n.x, __builtin_fmaf(f.rc.y, A.n.y, f.rc.z * A.n.z));
+  const float dp = __builtin_fmaf(-f.c.x, A.n.x, __builtin_fmaf(-f.c.y, A.n.y, __builtin_fmaf(-f.c.z, A.n.z, an)));
+  const float ob = __builtin_fmaf(__builtin_fabsf(A.n.x), f.h.x, __builtin_fmaf(__builtin_fabsf(A.n.y), f.h.y, __builtin_fabsf(A.n.z) * f.h.z)) * 1.001f;
+  const float L = __builtin_amdgcn_sqrtf(__builtin_fmaf(A.ac.x, A.ac.x, __builtin_fmaf(A.ac.y, A.ac.y, A.ac.z * A.ac.z))) * 1.002f;
+  const float sdp = __int_as_float(__float_as_int(dp) ^ (__float_as_int(det) & (int)0x80000000));
+  return (__builtin_fabsf(det) - ob > 1.5f * kc_max * f.smax) & (sdp + ob < -2.0f * L * kc_max);
+}
+
 // Walks the batches of one cell's list.  The batch headers are staged in LDS kHdrChunk at a time; for each
 // batch the bundle's leader ray, widened to contain every ray of the bundle, is tested against the batch's box first (one
 // lane per batch); for the batches that remain cull(centre, radius, half extents, transparent, inv_cos, ga, gb) decides
@@ -1809,6 +1826,37 @@ __global__ void __launch_bounds__(1024) k_order_scan_totals(uint32_t *__restrict
     __syncthreads();
   }
 }
+// Light lists (rt_lightlists.h, LightListsP): the lists are filled from the host's rectangles.  k_ll_count: references per
+// texel (one wavefront per rectangle); k_order_scan + k_order_scan_totals: exclusive scan; k_ll_starts: the lists' starts, and
+// a copy of them as fill cursors; k_ll_fill: the references, in the order the atomics grant (any order will do: a shadow
+// query asks whether some triangle of the list blocks, not which).
+__global__ void __launch_bounds__(256) k_ll_count(const LLRectD *__restrict__ rects, int n, const LLFaceD *__restrict__ faces, int R,
+                                                  uint32_t *__restrict__ counts) {
+  const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = lane_id();
+  if (w >= n) return;
+  const LLRectD r = rects[w];
+  const int a0 = (int)(r.rect & 255u), a1 = (int)((r.rect >> 8) & 255u), b0 = (int)((r.rect >> 16) & 255u), b1 = (int)(r.rect >> 24);
+  const int nw = a1 - a0 + 1, total = nw * (b1 - b0 + 1);
+  const uint32_t base = faces[r.face].base;
+  for (int e = lane; e < total; e += 64) atomicAdd(&counts[base + (uint32_t)((b0 + e / nw) * R + a0 + e % nw)], 1u);
+}
+__global__ void __launch_bounds__(256) k_ll_starts(uint32_t *__restrict__ offsets, const uint32_t *__restrict__ totals, int n, uint32_t all,
+                                                   uint32_t *__restrict__ cursor) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const uint32_t v = offsets[i] + totals[i / kScanTile]; offsets[i] = v; cursor[i] = v; }
+  else if (i == n) offsets[n] = all;
+}
+__global__ void __launch_bounds__(256) k_ll_fill(const LLRectD *__restrict__ rects, int n, const LLFaceD *__restrict__ faces, int R,
+                                                 uint32_t *__restrict__ cursor, LLRef *__restrict__ refs) {
+  const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = lane_id();
+  if (w >= n) return;
+  const LLRectD r = rects[w];
+  const int a0 = (int)(r.rect & 255u), a1 = (int)((r.rect >> 8) & 255u), b0 = (int)((r.rect >> 16) & 255u), b1 = (int)(r.rect >> 24);
+  const int nw = a1 - a0 + 1, total = nw * (b1 - b0 + 1);
+  const uint32_t base = faces[r.face].base;
+  LLRef ref; ref.tri = r.tri; ref.rect = r.rect;
+  for (int e = lane; e < total; e += 64) refs[atomicAdd(&cursor[base + (uint32_t)((b0 + e / nw) * R + a0 + e % nw)], 1u)] = ref;
+}
 __global__ void __launch_bounds__(256) k_order_place(GridP g, const SOrigin *__restrict__ sorg, const Ctl *__restrict__ ctl, int level,
                                                      int node_base, int parts, uint32_t *__restrict__ bucket, const uint32_t *__restrict__ totals,
                                                      uint32_t *__restrict__ order) {
@@ -2000,9 +2048,12 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 struct ShadowArgs {
   GridP g; ShadeP sp; const SOrigin *sorg; const int32_t *rand_rank; float *ts_out; long long ts_stride; Ctl *ctl;
   int level, node_base; const uint32_t *order;
+  LightListsP ll;
 };
-template <bool COUNT, bool RECTEST, bool ENDS>
+// LL: tickets whose walks all end at one point light are answered from that light's lists where they can be (below)
+template <bool COUNT, bool RECTEST, bool ENDS, bool LL = false>
 __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow(ShadowArgs args) {
+  static_assert(!LL || (!COUNT && RECTEST && !ENDS), "the light lists go with the fan of a point light's shadow rays, and not with the counting variant");
   const GridP &g = args.g;
   const ShadeP &sp = args.sp;
   const SOrigin *__restrict__ sorg = args.sorg;
@@ -2026,6 +2077,7 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
   Tickets tickets((unsigned long long)total);
+  uint32_t nListed = 0, nListFell = 0;  // tickets answered from the light lists / tried and walked after all
   for (;;) {
     uint32_t base;
     if (!tickets.take(ticket_counters(fresh_arg<Ctl *>(offsetof(ShadowArgs, ctl)), 1, fresh_arg<int>(offsetof(ShadowArgs, level))), lane, base)) break;
@@ -2124,6 +2176,162 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
           ticket_fan = make_fan(alive, a, lane_bcast3(light, first), wave_max(alive ? dmax : 0.0f) * 1.00001f);
       }
     }
+    // One triangle for one shadow ray: 0 = no effect, 2 = accepted hit of a transparent triangle, 3 = opaque
+    // blocker inside (1e-5, dmax); the filter decides what it can prove, tri_test the rest (:700-711).
+    // react(verdict, kt) runs, with all lanes of the caller active, only when some lane passed the first slab.
+    auto test = [&](const float *R, f3 to, f3 tr, f3 tm, float kc, int cur, float tdmax, auto &&react) {
+      const RecA A = rec_a(R);
+      PlTest t;
+      const bool p1 = pl_stage1(A.n, A.ac, A.q, tr, tm, kc, t);
+      if (wave_any(p1)) {
+        asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into the per-lane one
+        bool s3 = false;
+        int verdict = 0;
+        float kt = 0.0f;
+        if (p1) verdict = shadow_verdict(R, A, t, to, tr, tm, kc, g.lmax, tdmax, kt, s3);
+        if (COUNT) { nS2++; nS3 += __ballot(s3) != 0; nEx += __ballot(verdict == 1) != 0; }
+        if (verdict != 0) {
+          const int id = rec_id(R);
+          if (id == cur) {
+            verdict = 0;
+          } else if (verdict == 1) {
+            float d, u, v;
+            bool full = false;
+            verdict = !exact_test(g, id, to, tr, d, u, v, COUNT ? &full : nullptr) ? 0 : kt > 0.0f ? 2 : (d > 0.00001f && d < tdmax) ? 3 : 0;
+            if (COUNT && full) nFull++;
+          }
+        }
+        react(verdict, kt);
+        return true;
+      }
+      return false;
+    };
+    if (LL) {
+      ph.end<0>();
+      // The light's lists instead of the walk.  The ticket's hit points look at one point light (ticket_fan); every
+      // walking lane finds its texel on the cube around the light; the lists of the texels the ticket covers hold every
+      // triangle the exact test can accept for any of its rays (rt_lightlists.h).  One lane per reference: the triangle's
+      // record is culled for the whole fan (plane behind the rays, fan_slabs_pass), what is left goes through LDS to the
+      // test every lane runs.  A ray none of these triangles blocks is lit.  A ray one of them blocks is in shadow if its
+      // own walk passes a cell of the triangle's voxel box, i.e. a cell that lists it: the reference's scan finds a
+      // blocker there at the latest (voxelize.c:615-738 stops at the first); the walk's cells are stepped through without
+      // looking at their lists.  Where that fails, or the ticket does not fit the lists (rays on several faces, outside the
+      // face's window, origins beyond the norm the lists were built for, too many texels), the ticket takes the walk below.
+      const LightListsP ll = fresh_arg<LightListsP>(offsetof(ShadowArgs, ll));
+      const unsigned long long walking = __ballot(alive);
+      if (ll.on && ticket_fan.on && walking != 0) {
+        nListFell++;
+        const int first = __ffsll(walking) - 1;
+        const int light_i = __builtin_amdgcn_readlane(slot, first);
+        const f3 d = sub3(a, ticket_fan.L);
+        const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
+        const int ax = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
+        const float dw = ax == 0 ? d.x : ax == 1 ? d.y : d.z;
+        const float du = ax == 0 ? d.y : d.x, dv = ax == 2 ? d.y : d.z;
+        const float aw = __builtin_fabsf(dw);
+        const float p = du / aw, q = dv / aw;
+        const int face = ax * 2 + (dw < 0.0f ? 1 : 0);
+        const int face0 = __builtin_amdgcn_readlane(face, first);
+        const LLFaceD F = ll.faces[light_i * 6 + face0];
+        const bool fits = !alive || (face == face0 && p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1 && onorm <= ll.olim);
+        int tu = (int)((p - F.p0) * F.sp), tv = (int)((q - F.q0) * F.sq);
+        tu = tu < 0 ? 0 : tu > ll.R - 1 ? ll.R - 1 : tu;
+        tv = tv < 0 ? 0 : tv > ll.R - 1 ? ll.R - 1 : tv;
+        if (F.on != 0u && __ballot(!fits) == 0) {
+          const int U0 = -(int)wave_max(alive ? -(float)tu : -1e9f), U1 = (int)wave_max(alive ? (float)tu : -1.0f);
+          const int V0 = -(int)wave_max(alive ? -(float)tv : -1e9f), V1 = (int)wave_max(alive ? (float)tv : -1.0f);
+          const int nw = U1 - U0 + 1, ntex = nw * (V1 - V0 + 1);
+          if (ntex <= 64) {
+            uint32_t off = 0u, cnt = 0u;
+            if (lane < ntex) {
+              const uint32_t t = F.base + (uint32_t)((V0 + lane / nw) * ll.R + U0 + lane % nw);
+              off = ll.offsets[t]; cnt = ll.offsets[t + 1] - off;
+            }
+            const float onorm_all = wave_max(alive ? onorm : 0.0f);
+            int hit_id = -1;
+            bool open = alive, go = true;
+            int tx = U0, ty = V0;
+            for (int j = 0; j < ntex && go; j++) {
+              const uint32_t off_j = (uint32_t)__builtin_amdgcn_readlane((int)off, j), cnt_j = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+              for (uint32_t k0 = 0; k0 < cnt_j && go; k0 += 64u) {
+                const uint32_t at = k0 + (uint32_t)lane;
+                bool pass = false;
+                const v4f *R = nullptr;
+                if (at < cnt_j) {
+                  const LLRef ref = ll.refs[off_j + at];
+                  const int ra0 = (int)(ref.rect & 255u), rb0 = (int)((ref.rect >> 16) & 255u);
+                  // (a triangle whose rectangle covers several of the ticket's texels is taken at the first of them)
+                  if (tx == (ra0 > U0 ? ra0 : U0) && ty == (rb0 > V0 ? rb0 : V0)) {
+                    R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)ref.tri);
+                    const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+                    RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
+                    const float kc_max = __builtin_fmaf(r0.w, onorm_all, r2.w);
+                    pass = !fan_plane_behind(A, r4.z, kc_max, ticket_fan) &&
+                           fan_slabs_pass(A, mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), kc_max, r0.w, r2.w, ticket_fan);
+                  }
+                }
+                unsigned long long todo = __ballot(pass);
+                constexpr int kSlots = kSliceFloats / kRecFloats;
+                while (todo != 0 && go) {
+                  const int before = __popcll(todo & lanes_below(lane));
+                  const bool mine = ((todo >> lane) & 1ull) != 0 && before < kSlots;
+                  if (mine) {
+                    v4f *D = reinterpret_cast<v4f *>(slice + before * kRecFloats);
+                    const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+                    D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4;
+                  }
+                  const unsigned long long placed = __ballot(mine);
+                  todo &= ~placed;
+                  __builtin_amdgcn_wave_barrier();
+                  const int n = __popcll(placed);
+                  for (int q2 = 0; q2 < n && go; q2++) {
+                    const float *Rj = slice + q2 * kRecFloats;
+                    const float kc = open ? __builtin_fmaf(Rj[3], onorm, Rj[11]) : -INFINITY;
+                    test(Rj, a, r, pm, kc, current, dmax, [&](int verdict, float) {
+                      if (verdict == 3) { hit_id = rec_id(Rj); open = false; }
+                      go = __ballot(open) != 0;
+                    });
+                  }
+                  __builtin_amdgcn_wave_barrier();
+                }
+              }
+              if (++tx > U1) { tx = U0; ty++; }
+            }
+            // the candidate blockers against the walks
+            bool need = alive && hit_id >= 0, failed = false;
+            if (__ballot(need) != 0) {
+              int lo0 = 0, lo1 = 0, lo2 = 0, hi0 = -1, hi1 = -1, hi2 = -1, vi = 0, vj = 0, vk = 0;
+              if (need) {
+                const int32_t *bx = ll.tri_box + 6 * (size_t)hit_id;
+                lo0 = bx[0]; lo1 = bx[1]; lo2 = bx[2]; hi0 = bx[3]; hi1 = bx[4]; hi2 = bx[5];
+                cell_to_voxel(g, w.cell, vi, vj, vk);
+              }
+              Walk v = w;
+              const int si = r.x > 0.0f ? 1 : -1, sj = r.y > 0.0f ? 1 : -1, sk = r.z > 0.0f ? 1 : -1;
+              for (;;) {
+                if (need && vi >= lo0 && vi <= hi0 && vj >= lo1 && vj <= hi1 && vk >= lo2 && vk <= hi2) need = false;
+                if (__ballot(need) == 0) break;
+                if (need) {  // walk_step, with the voxel's indices instead of the cell's
+                  const float xn = v.tx + v.dtx, yn = v.ty + v.dty, zn = v.tz + v.dtz;
+                  const bool xy = xn < yn;
+                  const bool sx = xy & (xn < zn), sy = !xy & (yn < zn);
+                  v.tx = sx ? xn : v.tx; v.ty = sy ? yn : v.ty; v.tz = (sx | sy) ? v.tz : zn;
+                  v.nx -= sx ? 1 : 0; v.ny -= sy ? 1 : 0; v.nz -= (sx | sy) ? 0 : 1;
+                  vi += sx ? si : 0; vj += sy ? sj : 0; vk += (sx | sy) ? 0 : sk;
+                  if ((v.nx | v.ny | v.nz) < 0) { need = false; failed = true; }
+                }
+              }
+            }
+            if (__ballot(failed) == 0) {  // the ticket is settled
+              if (alive && hit_id >= 0) result = -1.0f;
+              alive = false;
+              nListed++; nListFell--;
+            }
+          }
+        }
+      }
+      ph.end<7>();
+    }
     ph.end<0>();
     for (;;) {
       const unsigned long long m = __ballot(alive);
@@ -2141,36 +2349,6 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
       const unsigned long long hist_w0 = nWave, hist_l0 = nLane;
 #endif
       bool proc;  // this lane's current cell is fully tested (or the ray blocked) after this step
-      // One triangle for one shadow ray: 0 = no effect, 2 = accepted hit of a transparent triangle, 3 = opaque
-      // blocker inside (1e-5, dmax); the filter decides what it can prove, tri_test the rest (:700-711).
-      // react(verdict, kt) runs, with all lanes of the caller active, only when some lane passed the first slab.
-      auto test = [&](const float *R, f3 to, f3 tr, f3 tm, float kc, int cur, float tdmax, auto &&react) {
-        const RecA A = rec_a(R);
-        PlTest t;
-        const bool p1 = pl_stage1(A.n, A.ac, A.q, tr, tm, kc, t);
-        if (wave_any(p1)) {
-          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into the per-lane one
-          bool s3 = false;
-          int verdict = 0;
-          float kt = 0.0f;
-          if (p1) verdict = shadow_verdict(R, A, t, to, tr, tm, kc, g.lmax, tdmax, kt, s3);
-          if (COUNT) { nS2++; nS3 += __ballot(s3) != 0; nEx += __ballot(verdict == 1) != 0; }
-          if (verdict != 0) {
-            const int id = rec_id(R);
-            if (id == cur) {
-              verdict = 0;
-            } else if (verdict == 1) {
-              float d, u, v;
-              bool full = false;
-              verdict = !exact_test(g, id, to, tr, d, u, v, COUNT ? &full : nullptr) ? 0 : kt > 0.0f ? 2 : (d > 0.00001f && d < tdmax) ? 3 : 0;
-              if (COUNT && full) nFull++;
-            }
-          }
-          react(verdict, kt);
-          return true;
-        }
-        return false;
-      };
       if (mode == kCellMode) {
         proc = in_group;
         // lanes outside the cell, and blocked ones, test with kc = -inf: rejected by the first slab
@@ -2286,6 +2464,11 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
   RT_TICKET(if (level == 0) TicketLog::life(1, lane, busy, born);)
   ph.end<0>();
   ph.flush(8, lane);
+  if (LL && lane == 0 && (nListed | nListFell) != 0) {
+    Ctl *ctl = fresh_arg<Ctl *>(offsetof(ShadowArgs, ctl));
+    atomicAdd(&ctl->stat[kShadListTickets], (unsigned long long)nListed);
+    atomicAdd(&ctl->stat[kShadListFallbacks], (unsigned long long)nListFell);
+  }
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       nS += __shfl_down(nS, off); nT += __shfl_down(nT, off); nQ += __shfl_down(nQ, off); nW += __shfl_down(nW, off);

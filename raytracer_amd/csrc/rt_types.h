@@ -142,6 +142,24 @@ struct ShadeP {
   float total_flux, distmod;
 };
 
+// Light lists (rt_lightlists.h): around every point light the six faces of a cube, a window of each face cut into
+// R x R texels, a texel listing the triangles a shadow ray seen from the light in that texel can be blocked by.
+// refs[offsets[t] .. offsets[t + 1]) is texel t's list; a reference carries its triangle's whole texel rectangle, so that a
+// wavefront that looks at several texels takes each triangle once (at the first texel of the rectangle it looks at).
+struct LLRef { int32_t tri; uint32_t rect; };  // rect = a0 | a1 << 8 | b0 << 16 | b1 << 24 (texel columns a0..a1, rows b0..b1)
+struct LLFaceD { float p0, q0, sp, sq, p1, q1; uint32_t base, on; };  // column floor((p - p0) sp), row floor((q - q0) sq); base: the face's first texel
+struct LLRectD { uint32_t face; uint32_t rect; int32_t tri; };
+struct LightListsP {
+  const uint32_t *offsets;
+  const LLRef *refs;
+  const LLFaceD *faces;   // [light * 6 + face]
+  const int32_t *tri_box; // per triangle the voxel index box lo[3], hi[3] of this frame's grid
+  float olim;             // the lists are complete for rays whose origin's norm is at most this
+  int32_t R;              // texels per face edge (<= 256)
+  int32_t on;
+  int32_t pad;
+};
+
 // Device-side control block of one chunk: queue lengths and statistics (the allocation continues with the ticket counters
 // of the persistent kernels, kCtlBytes in all).
 struct Ctl {
@@ -154,7 +172,7 @@ struct QueueCaps { int32_t cap[kMaxLevels + 1]; };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
             kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests,
             kNearStage2, kNearStage3, kNearExact, kShadStage2, kShadStage3, kShadExact,
-            kNearVisits, kShadVisits, kNearBatches, kNearCulled, kShadBatches, kShadCulled, kNearFull, kShadFull, kStatCount };
+            kNearVisits, kShadVisits, kNearBatches, kNearCulled, kShadBatches, kShadCulled, kNearFull, kShadFull, kShadListTickets, kShadListFallbacks, kStatCount };
 constexpr int kTotals = 40;  // frame totals: kStatCount counters, then the queue length of every level
 static_assert(kStatCount <= 32 && kStatCount + kMaxLevels <= kTotals, "the statistics fit the control block and the totals buffer");
 

@@ -16,6 +16,7 @@
 
 #include "../../include/rtgpu.h"
 #include "rt_kernels.h"
+#include "rt_lightlists.h"
 
 using namespace rt;
 
@@ -147,6 +148,15 @@ struct rtgpu_ctx {
   std::vector<int32_t> up_sid;
   std::vector<rtgpu_planar_light> up_planar;
   size_t cap_nt = 0, cap_ns = 0, cap_nl = 0, cap_npl = 0;  // what the scene's device arrays were allocated for
+  // light lists (rt_lightlists.h): built at the first frame of a scene without transparent triangles that has point lights
+  bool opt_light_lists = true;  // option "light_lists"
+  bool ll_tried = false;        // the uploaded scene's lists were built, or found not to apply
+  bool all_opaque = false;      // no triangle of the scene is transparent
+  LightListsP ll = {};
+  uint32_t *d_ll_offsets = nullptr;
+  LLRef *d_ll_refs = nullptr;
+  LLFaceD *d_ll_faces = nullptr;
+  size_t cap_ll_texels = 0, cap_ll_refs = 0, cap_ll_faces = 0;
   // timing
   std::vector<TimedSpan> spans;
   rtgpu_timings timings = {};
@@ -460,6 +470,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba); dev_free(&c->d_gammas); dev_free(&c->h_map);
   dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_order); dev_free(&c->d_ctl); dev_free(&c->d_totals);
+  dev_free(&c->d_ll_offsets); dev_free(&c->d_ll_refs); dev_free(&c->d_ll_faces);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -494,6 +505,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "queue_margin")) { if (value < 1 || value > 100000) return fail(c, RTGPU_E_INVALID_PARAM, "queue_margin out of range"); c->queue_margin_permille = (int)value; }
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
+  else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
   else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
   return RTGPU_OK;
@@ -580,6 +592,9 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   size_t transparent = 0;
   for (int t = 0; t < s->nt; t++) transparent += s->surfaces[s->sid[t]].kt > 0.0f ? 1 : 0;
   c->mostly_opaque = 2 * transparent < (size_t)s->nt;
+  c->all_opaque = transparent == 0;
+  c->ll_tried = false;
+  c->ll.on = 0;
   c->chunk_tiles_cap = 0;
   c->have_ratio = false;
   for (int L = 0; L < kMaxLevels; L++) c->ratio[L] = L == 0 ? 1.0 : 0.0;
@@ -615,6 +630,74 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   c->have_scene = true;
   return RTGPU_OK;
 }
+
+namespace {
+// The light lists of the uploaded scene (rt_lightlists.h), once per scene: the rectangles on the host, the lists on the
+// device.  A scene they do not apply to (a transparent triangle, no point light), or whose lists would be larger than
+// kLLMaxRefs references even with coarser texels, goes without: its shadow queries all take the walk.
+constexpr uint64_t kLLMaxRefs = 128ull << 20;
+int ensure_light_lists(rtgpu_ctx *c) {
+  if (c->ll_tried) return RTGPU_OK;
+  c->ll_tried = true;
+  c->ll.on = 0;
+  if (!c->all_opaque || c->nl <= 0 || c->nt <= 0) return RTGPU_OK;
+  std::vector<float> lp(3 * (size_t)c->nl);
+  for (int k = 0; k < c->nl; k++) for (int q = 0; q < 3; q++) lp[3 * (size_t)k + q] = c->lights[k].p[q];
+  LightListsHost h;
+  int R = getenv("RTGPU_LL_R") ? atoi(getenv("RTGPU_LL_R")) : 256;  // (experiment)
+  for (;;) {
+    build_light_rects(c->nt, c->up_verts.data(), c->nl, lp.data(), R, 0.0f, h);
+    if (h.refs <= kLLMaxRefs || R <= 32) break;
+    R /= 2;
+  }
+  if (h.refs > kLLMaxRefs || h.rects.empty() || h.refs == 0) return RTGPU_OK;
+  size_t ntexels = 0;
+  for (const LLFaceH &F : h.faces) if (F.on) ntexels += (size_t)R * R;
+  const int nscan = (int)((ntexels + kScanTile - 1) / kScanTile);
+  int rc;
+  if (ntexels + 1 + (size_t)nscan + 2 > c->cap_ll_texels) {
+    c->cap_ll_texels = 0;
+    if ((rc = dev_alloc(c, &c->d_ll_offsets, ntexels + 1 + (size_t)nscan + 2))) return rc;
+    c->cap_ll_texels = ntexels + 1 + (size_t)nscan + 2;
+  }
+  if ((size_t)h.refs > c->cap_ll_refs) {
+    c->cap_ll_refs = 0;
+    if ((rc = dev_alloc(c, &c->d_ll_refs, (size_t)h.refs))) return rc;
+    c->cap_ll_refs = (size_t)h.refs;
+  }
+  if (h.faces.size() > c->cap_ll_faces) {
+    c->cap_ll_faces = 0;
+    if ((rc = dev_alloc(c, &c->d_ll_faces, h.faces.size()))) return rc;
+    c->cap_ll_faces = h.faces.size();
+  }
+  static_assert(sizeof(LLRect) == sizeof(LLRectD) && sizeof(LLFaceH) == sizeof(LLFaceD), "host and device forms share one layout");
+  LLRectD *d_rects = nullptr;
+  uint32_t *d_cursor = nullptr;
+  if ((rc = dev_alloc(c, &d_rects, h.rects.size())) || (rc = dev_alloc(c, &d_cursor, ntexels))) { dev_free(&d_rects); dev_free(&d_cursor); return rc; }
+  uint32_t *totals = c->d_ll_offsets + ntexels + 1;
+  const int nr = (int)h.rects.size();
+  auto build = [&]() -> int {
+    HIPCHK(c, hipMemsetAsync(c->d_ll_offsets, 0, sizeof(uint32_t) * (ntexels + 1), c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rects, h.rects.data(), sizeof(LLRectD) * h.rects.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ll_faces, h.faces.data(), sizeof(LLFaceD) * h.faces.size(), hipMemcpyHostToDevice, c->stream));
+    const int wblocks = (int)(((size_t)nr * 64 + 255) / 256);
+    KLAUNCH(c, k_ll_count, dim3(wblocks), dim3(256), c->stream, (const LLRectD *)d_rects, nr, (const LLFaceD *)c->d_ll_faces, R, c->d_ll_offsets);
+    KLAUNCH(c, k_order_scan, dim3(nscan), dim3(1024), c->stream, c->d_ll_offsets, (int)ntexels, totals);
+    KLAUNCH(c, k_order_scan_totals, dim3(1), dim3(1024), c->stream, totals, nscan);
+    KLAUNCH(c, k_ll_starts, dim3((unsigned)((ntexels + 1 + 255) / 256)), dim3(256), c->stream, c->d_ll_offsets, (const uint32_t *)totals, (int)ntexels,
+            (uint32_t)h.refs, d_cursor);
+    KLAUNCH(c, k_ll_fill, dim3(wblocks), dim3(256), c->stream, (const LLRectD *)d_rects, nr, (const LLFaceD *)c->d_ll_faces, R, d_cursor, c->d_ll_refs);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RTGPU_OK;
+  };
+  rc = build();
+  dev_free(&d_rects); dev_free(&d_cursor);
+  if (rc) return rc;
+  c->ll.offsets = c->d_ll_offsets; c->ll.refs = c->d_ll_refs; c->ll.faces = c->d_ll_faces; c->ll.tri_box = c->d_box;
+  c->ll.olim = h.olim; c->ll.R = R; c->ll.on = 1; c->ll.pad = 0;
+  return RTGPU_OK;
+}
+}  // namespace
 
 int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   if (!c || !cam) return RTGPU_E_INVALID_PARAM;
@@ -748,6 +831,7 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   sp.total_flux = total_flux; sp.distmod = c->distmod;
   if (sp.nslots != c->shade.nslots) c->chunk_tiles_cap = 0;
   c->shade = sp;
+  if (c->opt_light_lists && (rc = ensure_light_lists(c))) return rc;
   c->have_frame = true;
   return RTGPU_OK;
 }
@@ -892,11 +976,16 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       }
       const int32_t *rr = c->npl > 0 ? c->d_rank : nullptr;
       const bool rectest = c->opt_record_test < 0 ? c->mostly_opaque : c->opt_record_test != 0;
-      const ShadowArgs sargs{c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], order};
+      LightListsP ll = c->ll;
+      ll.tri_box = c->d_box;
+      const bool lists = c->opt_light_lists && ll.on && c->filter && !c->opt_count && rectest && !ends;
+      if (!lists) ll.on = 0;
+      const ShadowArgs sargs{c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], order, ll};
 #define RT_LAUNCH_SHADOW(COUNT, RECTEST, ENDS) \
   KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, sargs)
 #define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)
       if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW2(true, true); else RT_LAUNCH_SHADOW2(true, false); }
+      else if (lists) KLAUNCH(c, (k_shadow<false, true, false, true>), dim3(pgrid), dim3(256), c->stream, sargs);
       else { if (rectest) RT_LAUNCH_SHADOW2(false, true); else RT_LAUNCH_SHADOW2(false, false); }
 #undef RT_LAUNCH_SHADOW2
 #undef RT_LAUNCH_SHADOW
@@ -1243,6 +1332,7 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   out->shadow_batches = (int64_t)h[kShadBatches]; out->shadow_batches_culled = (int64_t)h[kShadCulled];
   out->chunks = c->last_chunks; out->chunks_rerendered = c->last_rerendered;
   out->nearest_full_tests = (int64_t)h[kNearFull]; out->shadow_full_tests = (int64_t)h[kShadFull];
+  out->shadow_list_tickets = (int64_t)h[kShadListTickets]; out->shadow_list_fallbacks = (int64_t)h[kShadListFallbacks];
   return RTGPU_OK;
 }
 
@@ -1293,6 +1383,32 @@ int rtgpu_ticket_log(rtgpu_ctx *c, int which, uint32_t *out, int max_tickets, in
 #else
   (void)max_tickets;
 #endif
+  return RTGPU_OK;
+}
+
+int rtgpu_light_list_pairs(int64_t n, const float *verts, const float *lights, float olim, double *out) {
+  if (n < 0 || !verts || !lights || !out || !(olim > 0.0f)) return RTGPU_E_INVALID_PARAM;
+  for (int64_t k = 0; k < n; k++) {
+    const ll_detail::D3 P = {lights[3 * k], lights[3 * k + 1], lights[3 * k + 2]};
+    for (int f = 0; f < 6; f++) {
+      ll_detail::URect r;
+      double *o = out + (k * 6 + f) * 5;
+      if (face_rect(verts + 9 * k, P, (double)olim * 1.0002, f, r)) { o[0] = 1.0; o[1] = r.u0; o[2] = r.u1; o[3] = r.v0; o[4] = r.v1; }
+      else o[0] = o[1] = o[2] = o[3] = o[4] = 0.0;
+    }
+  }
+  return RTGPU_OK;
+}
+int rtgpu_light_list_rects(int32_t nt, const float *verts, int32_t nl, const float *lights, int32_t R, float olim, int64_t cap,
+                           uint32_t *rects, float *faces, float *olim_out, int64_t *n_rects, int64_t *refs) {
+  if (nt < 0 || nl < 0 || R < 1 || R > 256 || (nt > 0 && !verts) || (nl > 0 && !lights)) return RTGPU_E_INVALID_PARAM;
+  LightListsHost h;
+  build_light_rects(nt, verts, nl, lights, R, olim, h);
+  if (olim_out) *olim_out = h.olim;
+  if (n_rects) *n_rects = (int64_t)h.rects.size();
+  if (refs) *refs = (int64_t)h.refs;
+  if (faces) memcpy(faces, h.faces.data(), sizeof(LLFaceH) * h.faces.size());
+  if (rects) memcpy(rects, h.rects.data(), sizeof(LLRect) * (size_t)std::min<int64_t>(cap > 0 ? cap : 0, (int64_t)h.rects.size()));
   return RTGPU_OK;
 }
 

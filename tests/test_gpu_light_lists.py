@@ -1,0 +1,68 @@
+"""Shadow queries answered from the lights' lists (option "light_lists", scenes without transparent triangles) give the
+frame the cell walks give, bit for bit: the reference's shadow walk (src/voxelize.c:615-738) reports a blocker iff some
+triangle listed in a cell the ray passes blocks it, and the lists hold every triangle that can block
+(tests/test_light_lists_cpu.py) while a blocker found in them counts only if the ray's own walk passes one of its cells."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = [
+    ("scenes/temple/temple", {}, 320, 180),
+    ("scenes/temple/temple", {}, 960, 540),
+    ("scenes/temple/temple", {}, 1001, 333),
+    ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 800, 600),
+    ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 97, 61),
+]
+
+
+def frame(renderer, scene, lists):
+    renderer.set_option("light_lists", lists)
+    try:
+        renderer.upload(scene)
+        renderer.frame_begin()
+        renderer.counters()  # (totals since the last call)
+        out = renderer.render_host()
+        cnt = renderer.counters().asdict()
+    finally:
+        renderer.set_option("light_lists", 1)
+    return out, cnt
+
+
+@pytest.mark.parametrize("prefix,over,w,h", CASES, ids=["%s_%dx%d" % (c[0].split("/")[1], c[2], c[3]) for c in CASES])
+def test_light_lists_on_and_off_give_the_same_frame(prefix, over, w, h):
+    os.chdir(ROOT)
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    scene = rt.Scene(os.path.join(ROOT, prefix), width=w, height=h, **over)
+    r = rt.Renderer(0)
+    try:
+        on, con = frame(r, scene, 1)
+        off, coff = frame(r, scene, 0)
+    finally:
+        r.close()
+    assert np.array_equal(on["ids"], off["ids"])
+    assert np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32))
+    assert np.array_equal(on["minmax"].view(np.uint32), off["minmax"].view(np.uint32))
+    print("%s %dx%d: %d tickets from the lists, %d fell back to the walk" % (prefix, w, h, con["shadow_list_tickets"], con["shadow_list_fallbacks"]))
+    assert coff["shadow_list_tickets"] == 0 and coff["shadow_list_fallbacks"] == 0
+    assert con["shadow_list_tickets"] > 0
+    if w >= 800:  # (at a low resolution an 8x8 tile of hit points covers more texels than a ticket takes from the lists)
+        assert con["shadow_list_tickets"] > 4 * con["shadow_list_fallbacks"], "the lists answer most of the tickets they are tried for"
+
+
+def test_scenes_the_lists_do_not_apply_to_go_without():
+    """A transparent triangle anywhere (ulica, pokoj's glass), or planar lights only: every shadow query takes the walk."""
+    os.chdir(ROOT)
+    r = rt.Renderer(0)
+    try:
+        for prefix, over in [("scenes/ulica/ulica", {}), ("scenes/s2/s2", {"atr": os.path.join(ROOT, "scenes/pokoj/s2.atr")})]:
+            scene = rt.Scene(os.path.join(ROOT, prefix), width=96, height=64, **over)
+            out, cnt = frame(r, scene, 1)
+            assert cnt["shadow_list_tickets"] == 0 and cnt["shadow_list_fallbacks"] == 0
+    finally:
+        r.close()

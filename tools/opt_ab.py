@@ -22,5 +22,9 @@ for spec in sys.argv[4:] or [""]:
         r.frame_begin(); r.render_host(); t = r.timings().asdict()
         if best is None or t["shadow_ms"] + t["nearest_ms"] < best["shadow_ms"] + best["nearest_ms"]:
             best = t
-    print(spec or "defaults", {k: round(v, 3) for k, v in best.items() if k.endswith("_ms")}, flush=True)
+    r.counters()
+    r.frame_begin(); r.render_host()
+    cn = r.counters().asdict()
+    print(spec or "defaults", {k: round(v, 3) for k, v in best.items() if k.endswith("_ms")},
+          {k: cn[k] for k in ("shadow_list_tickets", "shadow_list_fallbacks")}, flush=True)
     r.close()
