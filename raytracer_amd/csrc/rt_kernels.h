@@ -21,6 +21,12 @@
 #define RT_SHADOW_RAYCULL(RECTEST, ENDS) ((ENDS) || !(RECTEST))
 #endif
 #ifndef RT_FLAT
+#ifndef RT_LL_TEXELS
+#define RT_LL_TEXELS 4  // a ticket takes its lists from the finest level at which its hit points cover at most this many texels
+#endif
+#ifndef RT_WAVES_LL
+#define RT_WAVES_LL 6  // waves per SIMD of the shadow walk's instance with the light lists
+#endif
 #define RT_FLAT 64  // lists of up to this many records are culled record by record, 64 at a time, without the batch level (stream_cell; 0: never)
 #endif
 #ifndef RT_WAVES_ACC
@@ -1826,19 +1832,20 @@ __global__ void __launch_bounds__(1024) k_order_scan_totals(uint32_t *__restrict
     __syncthreads();
   }
 }
-// Light lists (rt_lightlists.h, LightListsP): the lists are filled from the host's rectangles.  k_ll_count: references per
+// Light lists (rt_lightlists.h, LightListsP): the lists are filled from the host's rectangles, once per level (level l has
+// texels of 2^l x 2^l texels of level 0: a texel index shifted right by l).  k_ll_count: references per
 // texel (one wavefront per rectangle); k_order_scan + k_order_scan_totals: exclusive scan; k_ll_starts: the lists' starts, and
 // a copy of them as fill cursors; k_ll_fill: the references, in the order the atomics grant (any order will do: a shadow
 // query asks whether some triangle of the list blocks, not which).
-__global__ void __launch_bounds__(256) k_ll_count(const LLRectD *__restrict__ rects, int n, const LLFaceD *__restrict__ faces, int R,
-                                                  uint32_t *__restrict__ counts) {
+__global__ void __launch_bounds__(256) k_ll_count(const LLRectD *__restrict__ rects, int n, const LLFaceD *__restrict__ faces, int R, int level,
+                                                  uint32_t level_base, uint32_t *__restrict__ counts) {
   const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = lane_id();
   if (w >= n) return;
   const LLRectD r = rects[w];
-  const int a0 = (int)(r.rect & 255u), a1 = (int)((r.rect >> 8) & 255u), b0 = (int)((r.rect >> 16) & 255u), b1 = (int)(r.rect >> 24);
-  const int nw = a1 - a0 + 1, total = nw * (b1 - b0 + 1);
-  const uint32_t base = faces[r.face].base;
-  for (int e = lane; e < total; e += 64) atomicAdd(&counts[base + (uint32_t)((b0 + e / nw) * R + a0 + e % nw)], 1u);
+  const int a0 = (int)(r.rect & 255u) >> level, a1 = (int)((r.rect >> 8) & 255u) >> level, b0 = (int)((r.rect >> 16) & 255u) >> level, b1 = (int)(r.rect >> 24) >> level;
+  const int nw = a1 - a0 + 1, total = nw * (b1 - b0 + 1), Rl = R >> level;
+  const uint32_t base = level_base + (faces[r.face].base >> (2 * level));
+  for (int e = lane; e < total; e += 64) atomicAdd(&counts[base + (uint32_t)((b0 + e / nw) * Rl + a0 + e % nw)], 1u);
 }
 __global__ void __launch_bounds__(256) k_ll_starts(uint32_t *__restrict__ offsets, const uint32_t *__restrict__ totals, int n, uint32_t all,
                                                    uint32_t *__restrict__ cursor) {
@@ -1846,16 +1853,16 @@ __global__ void __launch_bounds__(256) k_ll_starts(uint32_t *__restrict__ offset
   if (i < n) { const uint32_t v = offsets[i] + totals[i / kScanTile]; offsets[i] = v; cursor[i] = v; }
   else if (i == n) offsets[n] = all;
 }
-__global__ void __launch_bounds__(256) k_ll_fill(const LLRectD *__restrict__ rects, int n, const LLFaceD *__restrict__ faces, int R,
-                                                 uint32_t *__restrict__ cursor, LLRef *__restrict__ refs) {
+__global__ void __launch_bounds__(256) k_ll_fill(const LLRectD *__restrict__ rects, int n, const LLFaceD *__restrict__ faces, int R, int level,
+                                                 uint32_t level_base, uint32_t *__restrict__ cursor, LLRef *__restrict__ refs) {
   const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = lane_id();
   if (w >= n) return;
   const LLRectD r = rects[w];
-  const int a0 = (int)(r.rect & 255u), a1 = (int)((r.rect >> 8) & 255u), b0 = (int)((r.rect >> 16) & 255u), b1 = (int)(r.rect >> 24);
-  const int nw = a1 - a0 + 1, total = nw * (b1 - b0 + 1);
-  const uint32_t base = faces[r.face].base;
-  LLRef ref; ref.tri = r.tri; ref.rect = r.rect;
-  for (int e = lane; e < total; e += 64) refs[atomicAdd(&cursor[base + (uint32_t)((b0 + e / nw) * R + a0 + e % nw)], 1u)] = ref;
+  const int a0 = (int)(r.rect & 255u) >> level, a1 = (int)((r.rect >> 8) & 255u) >> level, b0 = (int)((r.rect >> 16) & 255u) >> level, b1 = (int)(r.rect >> 24) >> level;
+  const int nw = a1 - a0 + 1, total = nw * (b1 - b0 + 1), Rl = R >> level;
+  const uint32_t base = level_base + (faces[r.face].base >> (2 * level));
+  LLRef ref; ref.tri = r.tri; ref.rect = (uint32_t)a0 | (uint32_t)a1 << 8 | (uint32_t)b0 << 16 | (uint32_t)b1 << 24;  // the rectangle in this level's texels
+  for (int e = lane; e < total; e += 64) refs[atomicAdd(&cursor[base + (uint32_t)((b0 + e / nw) * Rl + a0 + e % nw)], 1u)] = ref;
 }
 __global__ void __launch_bounds__(256) k_order_place(GridP g, const SOrigin *__restrict__ sorg, const Ctl *__restrict__ ctl, int level,
                                                      int node_base, int parts, uint32_t *__restrict__ bucket, const uint32_t *__restrict__ totals,
@@ -2052,7 +2059,7 @@ struct ShadowArgs {
 };
 // LL: tickets whose walks all end at one point light are answered from that light's lists where they can be (below)
 template <bool COUNT, bool RECTEST, bool ENDS, bool LL = false>
-__global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow(ShadowArgs args) {
+__global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL : RT_WAVES) k_shadow(ShadowArgs args) {
   static_assert(!LL || (!COUNT && RECTEST && !ENDS), "the light lists go with the fan of a point light's shadow rays, and not with the counting variant");
   const GridP &g = args.g;
   const ShadeP &sp = args.sp;
@@ -2123,7 +2130,7 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
         slot_light(sp, slot, rand_rank ? rand_rank[node_base + nidx] : 0, b, lflux, lcol);
         light = b;
         r = ray3(a, b);
-        const float kt_cur = sp.surf[sp.tri_sid[current]].kt;
+        const float kt_cur = LL ? 0.0f : sp.surf[sp.tri_sid[current]].kt;  // (the instance with the light lists runs in scenes without a transparent triangle)
         bool lit_walk = true;
         if (kt_cur == 0.0f && dot3(r, ld3(sp.tri_aux + 4 * current)) <= 0.0f) { result = -1.0f; lit_walk = false; }  // :640-644
         if (lit_walk) {
@@ -2138,12 +2145,13 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
             pl_ray(a, r, pm, onorm, odr);
             alive = true;
             if (COUNT) { nW++; nS++; }
-            if (!cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
+            // (with the light lists a ticket seldom walks: its walks go to their first non-empty cells only if it does)
+            if (!LL && !cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
           }
         }
       }
     }
-    if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
+    if (!LL && alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
       mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
       if (COUNT) nT += mycnt;
     }
@@ -2238,13 +2246,17 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
         tu = tu < 0 ? 0 : tu > ll.R - 1 ? ll.R - 1 : tu;
         tv = tv < 0 ? 0 : tv > ll.R - 1 ? ll.R - 1 : tv;
         if (F.on != 0u && __ballot(!fits) == 0) {
-          const int U0 = -(int)wave_max(alive ? -(float)tu : -1e9f), U1 = (int)wave_max(alive ? (float)tu : -1.0f);
-          const int V0 = -(int)wave_max(alive ? -(float)tv : -1e9f), V1 = (int)wave_max(alive ? (float)tv : -1.0f);
-          const int nw = U1 - U0 + 1, ntex = nw * (V1 - V0 + 1);
+          int U0 = -(int)wave_max(alive ? -(float)tu : -1e9f), U1 = (int)wave_max(alive ? (float)tu : -1.0f);
+          int V0 = -(int)wave_max(alive ? -(float)tv : -1e9f), V1 = (int)wave_max(alive ? (float)tv : -1.0f);
+          // the finest level at which the ticket's box of texels is small (a texel of level l is 2^l x 2^l of level 0's)
+          int level = 0;
+          while (level + 1 < ll.levels && ((U1 >> level) - (U0 >> level) + 1) * ((V1 >> level) - (V0 >> level) + 1) > RT_LL_TEXELS) level++;
+          U0 >>= level; U1 >>= level; V0 >>= level; V1 >>= level;
+          const int nw = U1 - U0 + 1, ntex = nw * (V1 - V0 + 1), Rl = ll.R >> level;
           if (ntex <= 64) {
             uint32_t off = 0u, cnt = 0u;
             if (lane < ntex) {
-              const uint32_t t = F.base + (uint32_t)((V0 + lane / nw) * ll.R + U0 + lane % nw);
+              const uint32_t t = ll_level_base(ll.texels0, level) + (F.base >> (2 * level)) + (uint32_t)((V0 + lane / nw) * Rl + U0 + lane % nw);
               off = ll.offsets[t]; cnt = ll.offsets[t + 1] - off;
             }
             const float onorm_all = wave_max(alive ? onorm : 0.0f);
@@ -2304,7 +2316,7 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
               if (need) {
                 const int32_t *bx = ll.tri_box + 6 * (size_t)hit_id;
                 lo0 = bx[0]; lo1 = bx[1]; lo2 = bx[2]; hi0 = bx[3]; hi1 = bx[4]; hi2 = bx[5];
-                cell_to_voxel(g, w.cell, vi, vj, vk);
+                (void)voxel_of(g, a, vi, vj, vk);  // (the walk still stands in its first cell, the hit point's voxel)
               }
               Walk v = w;
               const int si = r.x > 0.0f ? 1 : -1, sj = r.y > 0.0f ? 1 : -1, sk = r.z > 0.0f ? 1 : -1;
@@ -2329,6 +2341,11 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : RT_WAVES) k_shadow
             }
           }
         }
+      }
+      if (__ballot(alive) != 0) {  // the ticket walks after all: what the set-up left out
+        const GridP g = fresh_arg<GridP>(offsetof(ShadowArgs, g));
+        if (alive && !cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
+        if (alive) { mybeg = g.cell_start[w.cell]; mycnt = g.cell_start[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell]; }
       }
       ph.end<7>();
     }

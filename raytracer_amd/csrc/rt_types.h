@@ -147,7 +147,7 @@ struct ShadeP {
 // refs[offsets[t] .. offsets[t + 1]) is texel t's list; a reference carries its triangle's whole texel rectangle, so that a
 // wavefront that looks at several texels takes each triangle once (at the first texel of the rectangle it looks at).
 struct LLRef { int32_t tri; uint32_t rect; };  // rect = a0 | a1 << 8 | b0 << 16 | b1 << 24 (texel columns a0..a1, rows b0..b1)
-struct LLFaceD { float p0, q0, sp, sq, p1, q1; uint32_t base, on; };  // column floor((p - p0) sp), row floor((q - q0) sq); base: the face's first texel
+struct LLFaceD { float p0, q0, sp, sq, p1, q1; uint32_t base, on; };  // column floor((p - p0) sp), row floor((q - q0) sq) at level 0; base: the face's first texel there (base >> 2 l at level l)
 struct LLRectD { uint32_t face; uint32_t rect; int32_t tri; };
 struct LightListsP {
   const uint32_t *offsets;
@@ -155,10 +155,16 @@ struct LightListsP {
   const LLFaceD *faces;   // [light * 6 + face]
   const int32_t *tri_box; // per triangle the voxel index box lo[3], hi[3] of this frame's grid
   float olim;             // the lists are complete for rays whose origin's norm is at most this
-  int32_t R;              // texels per face edge (<= 256)
+  int32_t R;              // texels per face edge at level 0 (<= 256, a power of two)
   int32_t on;
-  int32_t pad;
+  int32_t levels;         // 1..4: level l has R >> l texels per face edge; its texels follow those of the levels before it
+  uint32_t texels0;       // texels of level 0 (level l: texels0 >> 2 l)
+  uint32_t pad[3];
 };
+// first texel of level l
+__host__ __device__ inline uint32_t ll_level_base(uint32_t texels0, int level) {
+  return level == 0 ? 0u : level == 1 ? texels0 : level == 2 ? texels0 + (texels0 >> 2) : texels0 + (texels0 >> 2) + (texels0 >> 4);
+}
 
 // Device-side control block of one chunk: queue lengths and statistics (the allocation continues with the ticket counters
 // of the persistent kernels, kCtlBytes in all).

@@ -150,6 +150,7 @@ struct rtgpu_ctx {
   size_t cap_nt = 0, cap_ns = 0, cap_nl = 0, cap_npl = 0;  // what the scene's device arrays were allocated for
   // light lists (rt_lightlists.h): built at the first frame of a scene without transparent triangles that has point lights
   bool opt_light_lists = true;  // option "light_lists"
+  int opt_ll_texels = 256;      // option "light_list_texels": texels per face edge of the finest level (a power of two, 8..256)
   bool ll_tried = false;        // the uploaded scene's lists were built, or found not to apply
   bool all_opaque = false;      // no triangle of the scene is transparent
   LightListsP ll = {};
@@ -506,6 +507,10 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
+  else if (!strcmp(name, "light_list_texels")) {
+    if (value < 8 || value > 256 || (value & (value - 1)) != 0) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_texels: a power of two, 8..256");
+    if (c->opt_ll_texels != (int)value) { c->opt_ll_texels = (int)value; c->ll_tried = false; c->ll.on = 0; }
+  }
   else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
   return RTGPU_OK;
@@ -644,15 +649,30 @@ int ensure_light_lists(rtgpu_ctx *c) {
   std::vector<float> lp(3 * (size_t)c->nl);
   for (int k = 0; k < c->nl; k++) for (int q = 0; q < 3; q++) lp[3 * (size_t)k + q] = c->lights[k].p[q];
   LightListsHost h;
-  int R = getenv("RTGPU_LL_R") ? atoi(getenv("RTGPU_LL_R")) : 256;  // (experiment)
+  int R = c->opt_ll_texels;
   for (;;) {
     build_light_rects(c->nt, c->up_verts.data(), c->nl, lp.data(), R, 0.0f, h);
     if (h.refs <= kLLMaxRefs || R <= 32) break;
     R /= 2;
   }
   if (h.refs > kLLMaxRefs || h.rects.empty() || h.refs == 0) return RTGPU_OK;
+  // levels: texels of 2^l x 2^l texels of level 0, down to 8 per face edge, four levels at most
+  size_t ntex0 = 0;
+  for (const LLFaceH &F : h.faces) if (F.on) ntex0 += (size_t)R * R;
+  int levels = 1;
+  while (levels < 4 && (R >> levels) >= 8) levels++;
+  uint32_t level_base[4] = {0, 0, 0, 0};
   size_t ntexels = 0;
-  for (const LLFaceH &F : h.faces) if (F.on) ntexels += (size_t)R * R;
+  uint64_t refs_all = 0;
+  for (int l = 0; l < levels; l++) {
+    level_base[l] = ll_level_base((uint32_t)ntex0, l);
+    ntexels += ntex0 >> (2 * l);
+    for (const LLRect &r : h.rects) {
+      const int a0 = (int)(r.rect & 255u) >> l, a1 = (int)((r.rect >> 8) & 255u) >> l, b0 = (int)((r.rect >> 16) & 255u) >> l, b1 = (int)(r.rect >> 24) >> l;
+      refs_all += (uint64_t)(a1 - a0 + 1) * (uint64_t)(b1 - b0 + 1);
+    }
+  }
+  if (refs_all > 2 * kLLMaxRefs) return RTGPU_OK;
   const int nscan = (int)((ntexels + kScanTile - 1) / kScanTile);
   int rc;
   if (ntexels + 1 + (size_t)nscan + 2 > c->cap_ll_texels) {
@@ -660,10 +680,10 @@ int ensure_light_lists(rtgpu_ctx *c) {
     if ((rc = dev_alloc(c, &c->d_ll_offsets, ntexels + 1 + (size_t)nscan + 2))) return rc;
     c->cap_ll_texels = ntexels + 1 + (size_t)nscan + 2;
   }
-  if ((size_t)h.refs > c->cap_ll_refs) {
+  if ((size_t)refs_all > c->cap_ll_refs) {
     c->cap_ll_refs = 0;
-    if ((rc = dev_alloc(c, &c->d_ll_refs, (size_t)h.refs))) return rc;
-    c->cap_ll_refs = (size_t)h.refs;
+    if ((rc = dev_alloc(c, &c->d_ll_refs, (size_t)refs_all))) return rc;
+    c->cap_ll_refs = (size_t)refs_all;
   }
   if (h.faces.size() > c->cap_ll_faces) {
     c->cap_ll_faces = 0;
@@ -681,12 +701,14 @@ int ensure_light_lists(rtgpu_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(d_rects, h.rects.data(), sizeof(LLRectD) * h.rects.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ll_faces, h.faces.data(), sizeof(LLFaceD) * h.faces.size(), hipMemcpyHostToDevice, c->stream));
     const int wblocks = (int)(((size_t)nr * 64 + 255) / 256);
-    KLAUNCH(c, k_ll_count, dim3(wblocks), dim3(256), c->stream, (const LLRectD *)d_rects, nr, (const LLFaceD *)c->d_ll_faces, R, c->d_ll_offsets);
+    for (int l = 0; l < levels; l++)
+      KLAUNCH(c, k_ll_count, dim3(wblocks), dim3(256), c->stream, (const LLRectD *)d_rects, nr, (const LLFaceD *)c->d_ll_faces, R, l, level_base[l], c->d_ll_offsets);
     KLAUNCH(c, k_order_scan, dim3(nscan), dim3(1024), c->stream, c->d_ll_offsets, (int)ntexels, totals);
     KLAUNCH(c, k_order_scan_totals, dim3(1), dim3(1024), c->stream, totals, nscan);
     KLAUNCH(c, k_ll_starts, dim3((unsigned)((ntexels + 1 + 255) / 256)), dim3(256), c->stream, c->d_ll_offsets, (const uint32_t *)totals, (int)ntexels,
-            (uint32_t)h.refs, d_cursor);
-    KLAUNCH(c, k_ll_fill, dim3(wblocks), dim3(256), c->stream, (const LLRectD *)d_rects, nr, (const LLFaceD *)c->d_ll_faces, R, d_cursor, c->d_ll_refs);
+            (uint32_t)refs_all, d_cursor);
+    for (int l = 0; l < levels; l++)
+      KLAUNCH(c, k_ll_fill, dim3(wblocks), dim3(256), c->stream, (const LLRectD *)d_rects, nr, (const LLFaceD *)c->d_ll_faces, R, l, level_base[l], d_cursor, c->d_ll_refs);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RTGPU_OK;
   };
@@ -694,7 +716,8 @@ int ensure_light_lists(rtgpu_ctx *c) {
   dev_free(&d_rects); dev_free(&d_cursor);
   if (rc) return rc;
   c->ll.offsets = c->d_ll_offsets; c->ll.refs = c->d_ll_refs; c->ll.faces = c->d_ll_faces; c->ll.tri_box = c->d_box;
-  c->ll.olim = h.olim; c->ll.R = R; c->ll.on = 1; c->ll.pad = 0;
+  c->ll.olim = h.olim; c->ll.R = R; c->ll.on = 1; c->ll.levels = levels;
+  c->ll.texels0 = (uint32_t)ntex0;
   return RTGPU_OK;
 }
 }  // namespace
@@ -985,7 +1008,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, sargs)
 #define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)
       if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW2(true, true); else RT_LAUNCH_SHADOW2(true, false); }
-      else if (lists) KLAUNCH(c, (k_shadow<false, true, false, true>), dim3(pgrid), dim3(256), c->stream, sargs);
+      else if (lists) KLAUNCH(c, (k_shadow<false, true, false, true>), dim3(c->waves_per_cu ? pgrid : c->num_cu * RT_WAVES_LL), dim3(256), c->stream, sargs);
       else { if (rectest) RT_LAUNCH_SHADOW2(false, true); else RT_LAUNCH_SHADOW2(false, false); }
 #undef RT_LAUNCH_SHADOW2
 #undef RT_LAUNCH_SHADOW

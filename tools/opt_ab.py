@@ -18,7 +18,7 @@ for spec in sys.argv[4:] or [""]:
         r.set_option(k, v)
     r.upload(sc)
     best = None
-    for _ in range(5):
+    for _ in range(int(os.environ.get("AB_FRAMES", "20"))):
         r.frame_begin(); r.render_host(); t = r.timings().asdict()
         if best is None or t["shadow_ms"] + t["nearest_ms"] < best["shadow_ms"] + best["nearest_ms"]:
             best = t
