@@ -285,10 +285,12 @@ int rtgpu_math_selfcheck(rtgpu_ctx *ctx, uint64_t mismatches[2]);
  * against the test itself.
  * rtgpu_light_list_pairs: for n (triangle, light) pairs (verts n x 9: i, j, k; lights n x 3) and rays whose origin
  * has a norm of at most olim, out[n][6][5] = per cube face (+x, -x, +y, -y, +z, -z) found (0 / 1) and the rectangle
- * u0, u1, v0, v1 in face coordinates (the two other axes in ascending order, divided by the dominant one's magnitude).
- * rtgpu_light_list_rects: the whole table for a scene as the library would build it with R x R texels per face
- * (olim <= 0: chosen from the scene): faces[nl * 6][8] = p0, q0, sp, sq, p1, q1, base, on (the last two as uint32
- * bits): the window of the face and the scale of its texels; rects[*n_rects][3] = face index (light * 6 + face), packed
+ * u0, u1, v0, v1 in face coordinates (the two other axes in ascending order, divided by the face axis' magnitude; the
+ * faces overlap: coordinates run over [-1.25, 1.25]).
+ * rtgpu_light_list_rects: the whole table for a scene as the library would build it with R x R texels per window
+ * (olim <= 0: chosen from the scene): faces[nl * 6 * 2][8] = per light, face and window (0: where most triangles are,
+ * 1: the whole face, for rays outside window 0) p0, q0, sp, sq, p1, q1, base, on (the last two as uint32 bits): the
+ * window and the scale of its texels; rects[*n_rects][3] = window index ((light * 6 + face) * 2 + window), packed
  * texel rectangle (columns a0 | a1 << 8, rows b0 << 16 | b1 << 24), triangle.  cap: room in rects (in rectangles);
  * *n_rects is the number there would be.  *refs: the sum of the rectangles' areas. */
 int rtgpu_light_list_pairs(int64_t n, const float *verts, const float *lights, float olim, double *out);

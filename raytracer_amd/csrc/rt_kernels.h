@@ -21,6 +21,7 @@
 #define RT_SHADOW_RAYCULL(RECTEST, ENDS) ((ENDS) || !(RECTEST))
 #endif
 #ifndef RT_FLAT
+constexpr float kLLFaceExt = 1.25f;  // (rt_lightlists.h: kFaceExt)
 #ifndef RT_LL_TEXELS
 #define RT_LL_TEXELS 4  // a ticket takes its lists from the finest level at which its hit points cover at most this many texels
 #endif
@@ -2231,17 +2232,23 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
         nListFell++;
         const int first = __ffsll(walking) - 1;
         const int light_i = __builtin_amdgcn_readlane(slot, first);
+        // the face of the first walking lane's hit point, for all lanes: faces overlap (coordinates up to kLLFaceExt), so a
+        // tile across a seam of the cube is still looked up on one face
         const f3 d = sub3(a, ticket_fan.L);
         const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
-        const int ax = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
+        const int ax_own = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
+        const int ax = __builtin_amdgcn_readlane(ax_own, first);
         const float dw = ax == 0 ? d.x : ax == 1 ? d.y : d.z;
         const float du = ax == 0 ? d.y : d.x, dv = ax == 2 ? d.y : d.z;
+        const bool neg = lane_bcast(dw, first) < 0.0f;
         const float aw = __builtin_fabsf(dw);
         const float p = du / aw, q = dv / aw;
-        const int face = ax * 2 + (dw < 0.0f ? 1 : 0);
-        const int face0 = __builtin_amdgcn_readlane(face, first);
-        const LLFaceD F = ll.faces[light_i * 6 + face0];
-        const bool fits = !alive || (face == face0 && p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1 && onorm <= ll.olim);
+        const bool onface = (dw < 0.0f) == neg && __builtin_fabsf(p) <= kLLFaceExt && __builtin_fabsf(q) <= kLLFaceExt;  // (a NaN: false)
+        const int face0 = ax * 2 + (neg ? 1 : 0);
+        LLFaceD F = ll.faces[(light_i * 6 + face0) * 2];
+        // window 0 if every hit point lies in it, else window 1 (the whole face)
+        if (F.on == 0u || __ballot(alive && !(p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1)) != 0) F = ll.faces[(light_i * 6 + face0) * 2 + 1];
+        const bool fits = !alive || (onface && p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1 && onorm <= ll.olim);
         int tu = (int)((p - F.p0) * F.sp), tv = (int)((q - F.q0) * F.sq);
         tu = tu < 0 ? 0 : tu > ll.R - 1 ? ll.R - 1 : tu;
         tv = tv < 0 ? 0 : tv > ll.R - 1 ? ll.R - 1 : tv;

@@ -45,16 +45,19 @@
 
 namespace rt {
 
-struct LLRect { uint32_t face; uint32_t rect; int32_t tri; };  // face = light * 6 + face; rect = a0 | a1 << 8 | b0 << 16 | b1 << 24 (texel columns a, rows b)
+struct LLRect { uint32_t face; uint32_t rect; int32_t tri; };  // face = (light * 6 + face) * 2 + window; rect = a0 | a1 << 8 | b0 << 16 | b1 << 24 (texel columns a, rows b)
 struct LLFaceH { float p0, q0, sp, sq, p1, q1; uint32_t base, on; };  // texel of (p, q): column floor((p - p0) sp), row floor((q - q0) sq); base: index of the face's first texel
 
 struct LightListsHost {
   int R = 0;
   float olim = 0.0f;
   std::vector<LLRect> rects;
-  std::vector<LLFaceH> faces;  // nl * 6
+  std::vector<LLFaceH> faces;  // nl * 6 * 2: per light and face window 0 and window 1
   uint64_t refs = 0;           // sum of the rectangles' areas
 };
+
+constexpr bool kWholeFaceWindow = false;  // window 1 of every face (measured: see build_light_rects)
+constexpr double kFaceExt = 1.25;  // a face's coordinates run over [-kFaceExt, kFaceExt]: the faces overlap, so that hit points on both sides of a seam can be looked up on one face
 
 namespace ll_detail {
 struct D3 { double x, y, z; };
@@ -111,13 +114,13 @@ inline bool face_rect(const float *v, ll_detail::D3 P, double olim, int f, ll_de
   for (int pass = 0; pass < 2; pass++) {
     double sigma;
     if (one_sign) { if (pass) break; sigma = DT > 0.0 ? 1.0 : -1.0; } else sigma = pass ? -1.0 : 1.0;
-    const double m = 1e-4;
+    const double m = kFaceExt + 1e-4;
     Poly poly; poly.n = 4;
-    poly.p[0] = -1 - m; poly.q[0] = -1 - m; poly.p[1] = 1 + m; poly.q[1] = -1 - m;
-    poly.p[2] = 1 + m; poly.q[2] = 1 + m; poly.p[3] = -1 - m; poly.q[3] = 1 + m;
+    poly.p[0] = -m; poly.q[0] = -m; poly.p[1] = m; poly.q[1] = -m;
+    poly.p[2] = m; poly.q[2] = m; poly.p[3] = -m; poly.q[3] = m;
     for (int k = 0; k < 3 && poly.n > 0; k++) {
       const double gl = len(G[k]);
-      const double T = 1.7325 * (tol + eta) + 3.5 * eps * gl + 1e-12 * (gl + 1.0);
+      const double T = 2.0315 * (tol + eta) + 4.1 * eps * gl + 1e-12 * (gl + 1.0);  // (|x| <= sqrt(1 + 2 kFaceExt^2) on the face)
       clip(poly, sigma * comp(G[k], o0), sigma * comp(G[k], o1), sigma * comp(G[k], ax) * sg + T);
     }
     for (int e = 0; e < poly.n; e++) {
@@ -128,8 +131,8 @@ inline bool face_rect(const float *v, ll_detail::D3 P, double olim, int f, ll_de
   if (u0 > u1) return false;
   const double wdn = 2e-5;
   u0 -= wdn; u1 += wdn; v0 -= wdn; v1 += wdn;
-  if (u1 < -1.0 || u0 > 1.0 || v1 < -1.0 || v0 > 1.0) return false;
-  out.tri = 0; out.u0 = std::max(u0, -1.0); out.u1 = std::min(u1, 1.0); out.v0 = std::max(v0, -1.0); out.v1 = std::min(v1, 1.0);
+  if (u1 < -kFaceExt || u0 > kFaceExt || v1 < -kFaceExt || v0 > kFaceExt) return false;
+  out.tri = 0; out.u0 = std::max(u0, -kFaceExt); out.u1 = std::min(u1, kFaceExt); out.v0 = std::max(v0, -kFaceExt); out.v1 = std::min(v1, kFaceExt);
   return true;
 }
 
@@ -139,7 +142,7 @@ inline void build_light_rects(int nt, const float *verts, int nl, const float *l
   using namespace ll_detail;
   out.R = R;
   out.rects.clear();
-  out.faces.assign((size_t)nl * 6, LLFaceH{0, 0, 0, 0, 0, 0, 0u, 0u});
+  out.faces.assign((size_t)nl * 12, LLFaceH{0, 0, 0, 0, 0, 0, 0u, 0u});
   out.refs = 0;
   if (nt <= 0 || nl <= 0) { out.olim = 0.0f; return; }
   double olim = olim_in;
@@ -166,9 +169,8 @@ inline void build_light_rects(int nt, const float *verts, int nl, const float *l
         URect r;
         if (face_rect(verts + 9 * (size_t)t, P, olim, f, r)) { r.tri = t; ur.push_back(r); }
       }
-      LLFaceH &F = out.faces[(size_t)li * 6 + f];
       if (ur.empty()) continue;
-      // the window
+      // the fine window
       double win[4];
       for (int side = 0; side < 4; side++) {
         edges.resize(ur.size());
@@ -185,22 +187,32 @@ inline void build_light_rects(int nt, const float *verts, int nl, const float *l
         if (win[1] - win[0] > 0.7 * (hi_u - lo_u)) { win[0] = lo_u; win[1] = hi_u; }
         if (win[3] - win[2] > 0.7 * (hi_v - lo_v)) { win[2] = lo_v; win[3] = hi_v; }
       }
-      const double wu = std::max(win[1] - win[0], 1e-4), wv = std::max(win[3] - win[2], 1e-4);
-      F.p0 = (float)(win[0] - 1e-6); F.q0 = (float)(win[2] - 1e-6);
-      F.p1 = (float)(win[0] + wu + 1e-6); F.q1 = (float)(win[2] + wv + 1e-6);
-      F.sp = (float)(R / ((double)F.p1 - (double)F.p0) * 0.99999); F.sq = (float)(R / ((double)F.q1 - (double)F.q0) * 0.99999);
-      F.on = 1u;
-      const double p0 = F.p0, q0 = F.q0, p1 = F.p1, q1 = F.q1, sp = F.sp, sq = F.sq;
-      auto texel = [R](double x, double x0, double s) {
-        const double t = std::floor((x - x0) * s);
-        return (int)std::min(std::max(t, 0.0), (double)(R - 1));
-      };
-      for (const URect &r : ur) {
-        if (r.u1 < p0 || r.u0 > p1 || r.v1 < q0 || r.v0 > q1) continue;
-        const int a0 = texel(std::max(r.u0, p0), p0, sp), a1 = texel(std::min(r.u1, p1), p0, sp);
-        const int b0 = texel(std::max(r.v0, q0), q0, sq), b1 = texel(std::min(r.v1, q1), q0, sq);
-        out.rects.push_back(LLRect{(uint32_t)(li * 6 + f), (uint32_t)a0 | (uint32_t)a1 << 8 | (uint32_t)b0 << 16 | (uint32_t)b1 << 24, r.tri});
-        out.refs += (uint64_t)(a1 - a0 + 1) * (uint64_t)(b1 - b0 + 1);
+      // window 0: where most rectangles are; window 1: the whole face, for the rays outside window 0 (left out when
+      // window 0 is nearly the whole face already: then window 0 is the whole face)
+      const bool whole = win[1] - win[0] > 1.8 * kFaceExt && win[3] - win[2] > 1.8 * kFaceExt;
+      for (int k = 0; k < (kWholeFaceWindow ? 2 : 1); k++) {
+        if (k == 1 && whole) break;
+        double w[4] = {win[0], win[1], win[2], win[3]};
+        if (k == 1 || whole) { w[0] = -kFaceExt; w[1] = kFaceExt; w[2] = -kFaceExt; w[3] = kFaceExt; }
+        const uint32_t fi = (uint32_t)((li * 6 + f) * 2 + k);
+        LLFaceH &F = out.faces[fi];
+        const double wu = std::max(w[1] - w[0], 1e-4), wv = std::max(w[3] - w[2], 1e-4);
+        F.p0 = (float)(w[0] - 1e-6); F.q0 = (float)(w[2] - 1e-6);
+        F.p1 = (float)(w[0] + wu + 1e-6); F.q1 = (float)(w[2] + wv + 1e-6);
+        F.sp = (float)(R / ((double)F.p1 - (double)F.p0) * 0.99999); F.sq = (float)(R / ((double)F.q1 - (double)F.q0) * 0.99999);
+        F.on = 1u;
+        const double p0 = F.p0, q0 = F.q0, p1 = F.p1, q1 = F.q1, sp = F.sp, sq = F.sq;
+        auto texel = [R](double x, double x0, double sc) {
+          const double t = std::floor((x - x0) * sc);
+          return (int)std::min(std::max(t, 0.0), (double)(R - 1));
+        };
+        for (const URect &r : ur) {
+          if (r.u1 < p0 || r.u0 > p1 || r.v1 < q0 || r.v0 > q1) continue;
+          const int a0 = texel(std::max(r.u0, p0), p0, sp), a1 = texel(std::min(r.u1, p1), p0, sp);
+          const int b0 = texel(std::max(r.v0, q0), q0, sq), b1 = texel(std::min(r.v1, q1), q0, sq);
+          out.rects.push_back(LLRect{fi, (uint32_t)a0 | (uint32_t)a1 << 8 | (uint32_t)b0 << 16 | (uint32_t)b1 << 24, r.tri});
+          out.refs += (uint64_t)(a1 - a0 + 1) * (uint64_t)(b1 - b0 + 1);
+        }
       }
     }
   }

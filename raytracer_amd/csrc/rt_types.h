@@ -152,7 +152,7 @@ struct LLRectD { uint32_t face; uint32_t rect; int32_t tri; };
 struct LightListsP {
   const uint32_t *offsets;
   const LLRef *refs;
-  const LLFaceD *faces;   // [light * 6 + face]
+  const LLFaceD *faces;   // [(light * 6 + face) * 2 + window]
   const int32_t *tri_box; // per triangle the voxel index box lo[3], hi[3] of this frame's grid
   float olim;             // the lists are complete for rays whose origin's norm is at most this
   int32_t R;              // texels per face edge at level 0 (<= 256, a power of two)

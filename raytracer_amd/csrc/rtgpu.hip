@@ -1430,7 +1430,7 @@ int rtgpu_light_list_rects(int32_t nt, const float *verts, int32_t nl, const flo
   if (olim_out) *olim_out = h.olim;
   if (n_rects) *n_rects = (int64_t)h.rects.size();
   if (refs) *refs = (int64_t)h.refs;
-  if (faces) memcpy(faces, h.faces.data(), sizeof(LLFaceH) * h.faces.size());
+  if (faces) memcpy(faces, h.faces.data(), sizeof(LLFaceH) * h.faces.size());  // nl * 12
   if (rects) memcpy(rects, h.rects.data(), sizeof(LLRect) * (size_t)std::min<int64_t>(cap > 0 ? cap : 0, (int64_t)h.rects.size()));
   return RTGPU_OK;
 }

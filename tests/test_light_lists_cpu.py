@@ -34,19 +34,26 @@ def shadow_ray(org, light):
     return rr * inv[:, None], np.sqrt(s2.astype(np.float64)).astype(F)
 
 
-def face_coords(org, light):
-    """The kernel's texel coordinates of a ray: face = dominant axis and sign of fl(a - P), (p, q) = the other two
-    components in ascending order over the dominant one's magnitude, binary32."""
+FACE_EXT = 1.25  # the faces of the cube overlap: a face's coordinates run over [-1.25, 1.25] (rt_lightlists.h)
+
+
+def face_coords(org, light, axis=None):
+    """The kernel's texel coordinates of a ray on the face of axis `axis` (None: the dominant axis of fl(a - P)) and of the
+    sign d has there: (p, q) = the other two components in ascending order over that component's magnitude, binary32.
+    on: the ray can be looked up on that face (both coordinates within FACE_EXT)."""
     d = (org - light).astype(F)
     ad = np.abs(d)
     ax = np.where((ad[:, 0] >= ad[:, 1]) & (ad[:, 0] >= ad[:, 2]), 0, np.where(ad[:, 1] >= ad[:, 2], 1, 2))
+    if axis is not None:
+        ax = np.full(len(d), axis)
     rows = np.arange(len(d))
     w = ad[rows, ax]
     o0 = np.where(ax == 0, 1, 0); o1 = np.where(ax == 2, 1, 2)
     with np.errstate(all="ignore"):
         p = (d[rows, o0] / w).astype(F); q = (d[rows, o1] / w).astype(F)
+        on = (np.abs(p) <= F(FACE_EXT)) & (np.abs(q) <= F(FACE_EXT))
     face = ax * 2 + (d[rows, ax] < 0)
-    return face, p, q
+    return face, p, q, on
 
 
 def make_light_cases(rng, n, scale, offset, aim, light_mode):
@@ -96,7 +103,6 @@ def test_every_blocker_lies_in_its_triangles_rectangle(scale, offset, aim, light
         blocker = acc & (d > F(0.00001)) & (d < dmax)
     if aim is not aim_anywhere and light_mode == "generic" and scale >= 0.01:  # (tiny triangles fail the test's |det| >= 1e-6)
         assert blocker.mean() > 0.2
-    face, p, q = face_coords(o, light)
     # rectangles for origins up to olim: in chunks of similar |o|, so that the tolerance is the one the ray's own norm gives
     onorm = np.sqrt((o.astype(np.float64) ** 2).sum(1))
     order = np.argsort(onorm)
@@ -109,13 +115,20 @@ def test_every_blocker_lies_in_its_triangles_rectangle(scale, offset, aim, light
         assert L.rtgpu_light_list_pairs(len(chunk), vv.ctypes.data, ll.ctypes.data, C.c_float(olim), oo.ctypes.data) == 0
         out[chunk] = oo
     rows = np.arange(n)
-    rc = out[rows, face]
-    inside = (rc[:, 0] > 0) & (p >= rc[:, 1]) & (p <= rc[:, 2]) & (q >= rc[:, 3]) & (q <= rc[:, 4])
-    missed = blocker & ~inside
-    assert not missed.any(), "%d blockers outside their triangle's rectangle, e.g. case %d" % (missed.sum(), np.flatnonzero(missed)[0])
-    if aim is aim_anywhere and light_mode == "generic":
-        # the rectangles are not everything: most rays that miss are outside
-        assert inside[~acc].mean() < 0.6
+    looked_up = 0
+    for axis in (None, 0, 1, 2):  # the ray's own face, and every face it can be looked up on from a neighbour's side
+        face, p, q, on = face_coords(o, light, axis)
+        rc = out[rows, face]
+        inside = (rc[:, 0] > 0) & (p >= rc[:, 1]) & (p <= rc[:, 2]) & (q >= rc[:, 3]) & (q <= rc[:, 4])
+        if axis is None:
+            assert on[np.isfinite(p) & np.isfinite(q)].all()  # (a ray whose origin is the light has no direction)
+        missed = blocker & on & ~inside
+        looked_up += int((blocker & on).sum())
+        assert not missed.any(), "%d blockers outside their triangle's rectangle on axis %s, e.g. case %d" % (missed.sum(), axis, np.flatnonzero(missed)[0])
+        if axis is None and aim is aim_anywhere and light_mode == "generic":
+            # the rectangles are not everything: most rays that miss are outside
+            assert inside[~acc].mean() < 0.6
+    assert looked_up > 1.15 * blocker.sum() or blocker.sum() == 0  # (some rays do lie in the overlap of two faces)
 
 
 def _scene_tables(name, R=256):
@@ -126,7 +139,7 @@ def _scene_tables(name, R=256):
     lights = np.ascontiguousarray(np.array([[sc.desc.lights[i].p[c] for c in range(3)] for i in range(sc.nl)], F))
     L = _lib()
     n_rects = C.c_int64(0); refs = C.c_int64(0); olim = C.c_float(0)
-    faces = np.zeros((sc.nl * 6, 8), F)
+    faces = np.zeros((sc.nl * 12, 8), F)
     assert L.rtgpu_light_list_rects(len(V), V.ctypes.data, sc.nl, lights.ctypes.data, R, C.c_float(0.0), 0, None, faces.ctypes.data,
                                     C.byref(olim), C.byref(n_rects), C.byref(refs)) == 0
     rects = np.zeros((n_rects.value, 3), np.uint32)
@@ -163,12 +176,16 @@ def test_a_scenes_table_lists_every_blocker_of_rays_between_its_surfaces_and_lig
     o, P, li = o[keep], P[keep], li[keep]
     n = len(o)
     r, dmax = shadow_ray(o, P)
-    face, p, q = face_coords(o, P)
-    fi = li * 6 + face
+    face, p, q, on = face_coords(o, P)
+    # window 0 of the ray's face if the ray lies in it, else window 1 (the whole face)
+    f0 = (li * 6 + face) * 2
+    W0 = faces[f0]
+    in0 = (W0[:, 7].view(np.uint32) != 0) & (p >= W0[:, 0]) & (p <= W0[:, 4]) & (q >= W0[:, 1]) & (q <= W0[:, 5])
+    fi = np.where(in0, f0, f0 + 1)
     Fp = faces[fi]
-    on = Fp[:, 7].view(np.uint32) != 0
-    inwin = on & (p >= Fp[:, 0]) & (p <= Fp[:, 4]) & (q >= Fp[:, 1]) & (q <= Fp[:, 5])
-    assert inwin.mean() > 0.6, "most rays between the scene's surfaces and its lights fall into the windows"
+    inwin = (Fp[:, 7].view(np.uint32) != 0) & (p >= Fp[:, 0]) & (p <= Fp[:, 4]) & (q >= Fp[:, 1]) & (q <= Fp[:, 5])
+    assert inwin.mean() > 0.95, "nearly all rays between the scene's surfaces and its lights can be looked up"
+    assert in0.mean() > 0.5
     with np.errstate(all="ignore"):
         tu = np.clip(((p - Fp[:, 0]).astype(F) * Fp[:, 2]).astype(F), 0, R - 1).astype(np.int64)
         tv = np.clip(((q - Fp[:, 1]).astype(F) * Fp[:, 3]).astype(F), 0, R - 1).astype(np.int64)
