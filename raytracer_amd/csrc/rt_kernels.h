@@ -2267,30 +2267,59 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
               off = ll.offsets[t]; cnt = ll.offsets[t + 1] - off;
             }
             const float onorm_all = wave_max(alive ? onorm : 0.0f);
+            RT_TICKET(tl.visits = (uint32_t)(level * 1000 + ntex);)  // (diagnostic build: what a ticket settled from the lists looked at)
             int hit_id = -1;
             bool open = alive, go = true;
             int tx = U0, ty = V0;
-            for (int j = 0; j < ntex && go; j++) {
-              const uint32_t off_j = (uint32_t)__builtin_amdgcn_readlane((int)off, j), cnt_j = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
-              for (uint32_t k0 = 0; k0 < cnt_j && go; k0 += 64u) {
-                const uint32_t at = k0 + (uint32_t)lane;
+            // First the references: those the ticket takes (each triangle once) are collected in LDS, one texel's list
+            // after the other, 64 list positions per pass; then the collected triangles' records, 64 per pass (and in
+            // between whenever the collection is full).
+            constexpr int kSlots = 32;                                   // records of the slice for a pass's survivors ...
+            constexpr int kIds = kSliceFloats - kSlots * kRecFloats;     // ... and the rest for the collected triangles
+            static_assert(kIds >= 128, "room for two passes' references");
+            int *ids = reinterpret_cast<int *>(slice + kSlots * kRecFloats);
+            int nids = 0;
+            int j = 0;
+            uint32_t k0 = 0u;
+            for (;;) {
+              while (j < ntex && nids <= kIds - 64) {
+                const uint32_t off_j = (uint32_t)__builtin_amdgcn_readlane((int)off, j), cnt_j = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+                if (k0 < cnt_j) {
+                  const uint32_t at = k0 + (uint32_t)lane;
+                  bool own = false;
+                  int id = 0;
+                  if (at < cnt_j) {
+                    const LLRef ref = ll.refs[off_j + at];
+                    const int ra0 = (int)(ref.rect & 255u), rb0 = (int)((ref.rect >> 16) & 255u);
+                    // (a triangle whose rectangle covers several of the ticket's texels is taken at the first of them)
+                    own = tx == (ra0 > U0 ? ra0 : U0) && ty == (rb0 > V0 ? rb0 : V0);
+                    id = ref.tri;
+                  }
+                  const unsigned long long m = __ballot(own);
+                  if (own) ids[nids + __popcll(m & lanes_below(lane))] = id;
+                  nids += __popcll(m);
+                  RT_TICKET(tl.batches += (uint32_t)__popcll(m);)
+                  k0 += 64u;
+                }
+                if (k0 >= cnt_j) {
+                  j++; k0 = 0u;
+                  if (++tx > U1) { tx = U0; ty++; }
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+              if (nids == 0) break;
+              for (int b0 = 0; b0 < nids && go; b0 += 64) {
                 bool pass = false;
                 const v4f *R = nullptr;
-                if (at < cnt_j) {
-                  const LLRef ref = ll.refs[off_j + at];
-                  const int ra0 = (int)(ref.rect & 255u), rb0 = (int)((ref.rect >> 16) & 255u);
-                  // (a triangle whose rectangle covers several of the ticket's texels is taken at the first of them)
-                  if (tx == (ra0 > U0 ? ra0 : U0) && ty == (rb0 > V0 ? rb0 : V0)) {
-                    R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)ref.tri);
-                    const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
-                    RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
-                    const float kc_max = __builtin_fmaf(r0.w, onorm_all, r2.w);
-                    pass = !fan_plane_behind(A, r4.z, kc_max, ticket_fan) &&
-                           fan_slabs_pass(A, mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), kc_max, r0.w, r2.w, ticket_fan);
-                  }
+                if (b0 + lane < nids) {
+                  R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)ids[b0 + lane]);
+                  const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+                  RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
+                  const float kc_max = __builtin_fmaf(r0.w, onorm_all, r2.w);
+                  pass = !fan_plane_behind(A, r4.z, kc_max, ticket_fan) &&
+                         fan_slabs_pass(A, mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), kc_max, r0.w, r2.w, ticket_fan);
                 }
                 unsigned long long todo = __ballot(pass);
-                constexpr int kSlots = kSliceFloats / kRecFloats;
                 while (todo != 0 && go) {
                   const int before = __popcll(todo & lanes_below(lane));
                   const bool mine = ((todo >> lane) & 1ull) != 0 && before < kSlots;
@@ -2303,6 +2332,7 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
                   todo &= ~placed;
                   __builtin_amdgcn_wave_barrier();
                   const int n = __popcll(placed);
+                  RT_TICKET(tl.tests += (uint32_t)n;)
                   for (int q2 = 0; q2 < n && go; q2++) {
                     const float *Rj = slice + q2 * kRecFloats;
                     const float kc = open ? __builtin_fmaf(Rj[3], onorm, Rj[11]) : -INFINITY;
@@ -2314,7 +2344,8 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
                   __builtin_amdgcn_wave_barrier();
                 }
               }
-              if (++tx > U1) { tx = U0; ty++; }
+              nids = 0;
+              if (!go || j >= ntex) break;
             }
             // the candidate blockers against the walks
             bool need = alive && hit_id >= 0, failed = false;

@@ -150,6 +150,7 @@ struct rtgpu_ctx {
   size_t cap_nt = 0, cap_ns = 0, cap_nl = 0, cap_npl = 0;  // what the scene's device arrays were allocated for
   // light lists (rt_lightlists.h): built at the first frame of a scene without transparent triangles that has point lights
   bool opt_light_lists = true;  // option "light_lists"
+  int opt_ll_levels = 4;        // option "light_list_levels": 1..4 levels of texels, each twice as coarse as the one before
   int opt_ll_texels = 256;      // option "light_list_texels": texels per face edge of the finest level (a power of two, 8..256)
   bool ll_tried = false;        // the uploaded scene's lists were built, or found not to apply
   bool all_opaque = false;      // no triangle of the scene is transparent
@@ -507,6 +508,10 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
+  else if (!strcmp(name, "light_list_levels")) {
+    if (value < 1 || value > 4) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_levels: 1..4");
+    if (c->opt_ll_levels != (int)value) { c->opt_ll_levels = (int)value; c->ll_tried = false; c->ll.on = 0; }
+  }
   else if (!strcmp(name, "light_list_texels")) {
     if (value < 8 || value > 256 || (value & (value - 1)) != 0) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_texels: a power of two, 8..256");
     if (c->opt_ll_texels != (int)value) { c->opt_ll_texels = (int)value; c->ll_tried = false; c->ll.on = 0; }
@@ -660,7 +665,8 @@ int ensure_light_lists(rtgpu_ctx *c) {
   size_t ntex0 = 0;
   for (const LLFaceH &F : h.faces) if (F.on) ntex0 += (size_t)R * R;
   int levels = 1;
-  while (levels < 4 && (R >> levels) >= 8) levels++;
+  const int max_levels = c->opt_ll_levels;
+  while (levels < max_levels && (R >> levels) >= 8) levels++;
   uint32_t level_base[4] = {0, 0, 0, 0};
   size_t ntexels = 0;
   uint64_t refs_all = 0;
