@@ -6,10 +6,12 @@
 // rectangles (k_ll_count, k_ll_fill) and k_shadow reads them.
 //
 // What has to hold.  The shadow ray of a hit point a towards the light P is o = a, r = fl((P - a) / |P - a|)
-// (vectormath.h:120-128), and the kernel picks the texel from d = fl(a - P): the face is d's dominant axis, the face
-// coordinates are (p, q) = (d_u / |d_w|, d_v / |d_w|) in binary32.  Claim: if tri_test accepts triangle T for (o, r) with
-// |o| <= olim and a distance d in (1e-5, dmax), then (p, q) lies in one of T's rectangles on that face.  Then a ray none of
-// whose texel's triangles blocks it is not blocked by any triangle at all, whatever cells its walk would have visited.
+// (vectormath.h:120-128), and the kernel picks the texel from d = fl(a - P): a face whose axis w has d_w != 0 of the
+// face's sign, with the face coordinates (p, q) = (d_u / |d_w|, d_v / |d_w|) in binary32, both within kFaceExt (the faces
+// overlap: a ray's own face is the one of d's dominant axis, where |p|, |q| <= 1, and a tile of hit points across a seam
+// is looked up on one face).  Claim: if tri_test accepts triangle T for (o, r) with |o| <= olim and a distance d in
+// (1e-5, dmax), then (p, q) lies in one of T's rectangles on that face.  Then a ray none of whose texel's triangles blocks
+// it is not blocked by any triangle at all, whatever cells its walk would have visited.
 //
 // Derivation.  With the triangle's vertices V0 = i, V1 = i + ij, V2 = i + ik as the test sees them (ij, ik rounded to
 // binary32) and w_k = V_k - P, the edge functions of a direction x are E_0(x) = x.(w_1 x w_2), E_1 = x.(w_2 x w_0),
@@ -17,13 +19,13 @@
 // the line through P along x meets the triangle's plane.  tri_test's numerators are, exactly on its float inputs,
 // tp* = r.(ik x (o - i)) = -E_1(r) + r.(ik x (a - P)), and likewise vp* and det* - tp* - vp* with E_2, E_0; det* = -D(r).
 // r is, component by component, within 2 eps of -c fl(a - P) for a common factor c, and fl(a - P) within eps of a - P, so
-// the last term is at most 3.1 eps L s (L the longest edge, s = |a - P| <= olim + |P|).
+// the last term is at most 3.1 eps L s (L the longest edge, s = |a - P| <= olim + |P|; twice that for the third numerator).
 // If tri_test accepts, then sign(det*) X* >= -(31.5 eps L (|o| + A) + 17.8 eps L^2) for each of the three numerators X*
 // (from its rounding bounds |det - det*| <= 8.9 eps L^2, |X - X*| <= 10.5 eps L (|o| + A), rt_math.h; A the largest vertex
 // norm; when det's sign is wrong, |det*| <= 8.9 eps L^2 and the conditions u >= 0, v >= 0, u + v <= 1 bound all three from
 // below with the other sign).  tol = 72 eps L (olim + A) + 28 eps L^2, half the filter's kc, is more than twice that.
-// Dividing by c |d_w| (= |x| up to 1e-6 for the face point x = d / |d_w|, |x| <= sqrt 3):
-//     sigma E_k(x) >= -T_k,   T_k = 1.7325 (tol + 3.2 eps L s) + 3.5 eps |w_a x w_b| + (double rounding),  sigma = sign(D(d))
+// Dividing by c |d_w| (= |x| up to 1e-6 for the face point x = d / |d_w|, |x| <= sqrt(1 + 2 kFaceExt^2) < 2.0315):
+//     sigma E_k(x) >= -T_k,   T_k = 2.0315 (tol + 6.4 eps L s) + 4.1 eps |w_a x w_b| + (double rounding),  sigma = sign(D(d))
 // on the face plane x = (p, q, +-1): three half planes in (p, q).  A blocker has its plane point between a and the light
 // unless the light lies within rounding of the plane: if |ij x ik| (h - delta) > 2.001 eps L^2 (8.9 s + 10.5 (olim + A))
 // and h - delta > 12 eps s (h the light's distance from the plane, delta = 4 eps s what the ray's line misses the light
@@ -36,7 +38,10 @@
 // Windows.  A face's texels cover a window [p0, p1] x [q0, q1] of the face, not the whole face: the part where the
 // rectangles are (a light far outside the scene sees it under a small angle).  A few very large triangles (a ground
 // plane) would blow the window up, so it is the box of the 1st to 99th percentile of the rectangles' edges unless that is
-// nearly everything.  A ray outside its face's window is not answered from the lists (its ticket takes the walk).
+// nearly everything.  A ray outside its face's window is not answered from the lists (its ticket takes the walk).  The
+// table has room for a second window per face, the whole face, for those rays (kWholeFaceWindow); it is left empty:
+// seen from a far light the scene falls into a few of its texels, and a ticket that looks there goes through most of
+// the scene's triangles (temple 3840x2160: the shadow kernel 1.56 -> 1.75 ms with it).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -56,7 +61,7 @@ struct LightListsHost {
   uint64_t refs = 0;           // sum of the rectangles' areas
 };
 
-constexpr bool kWholeFaceWindow = false;  // window 1 of every face (measured: see build_light_rects)
+constexpr bool kWholeFaceWindow = false;  // window 1 of every face (see above)
 constexpr double kFaceExt = 1.25;  // a face's coordinates run over [-kFaceExt, kFaceExt]: the faces overlap, so that hit points on both sides of a seam can be looked up on one face
 
 namespace ll_detail {

@@ -20,8 +20,12 @@ def _box(tris, lo, hi, sid):
         _quad(tris, p[q[0]], p[q[1]], p[q[2]], p[q[3]], sid)
 
 
-def write_scene(dirpath, seed, width=64, height=48):
-    """Writes <dirpath>/r.brs .atr .lgt .cam (and for some seeds .cfg); returns the prefix <dirpath>/r."""
+def write_scene(dirpath, seed, width=64, height=48, opaque=False, hard_lights=False):
+    """Writes <dirpath>/r.brs .atr .lgt .cam (and for some seeds .cfg); returns the prefix <dirpath>/r.
+    opaque: no surface is transparent or reflective (the same geometry, lights and camera as without).
+    hard_lights: the first lights are moved to where shadow rays are hardest for a table of directions around the light:
+    into the floor's plane (every ray from a floor point lies in that plane), onto a corner of the room's geometry,
+    into the crowded cluster."""
     rng = np.random.default_rng(seed)
     ext = float(rng.choice([3.0, 12.0, 60.0]))  # half extent of the room
     centre = rng.uniform(-1.0, 1.0, 3) * float(rng.choice([0.0, 10.0, 500.0]))
@@ -89,13 +93,22 @@ def write_scene(dirpath, seed, width=64, height=48):
     with open(prefix + ".atr", "w") as f:
         f.write("%d\n" % len(surf))
         for s in surf:
-            f.write(" ".join("%g" % (x * (rng.uniform(0.8, 1.0) if k in (0, 1, 7, 9) else 1.0)) for k, x in enumerate(s)) + "\n")
+            vals = [x * (rng.uniform(0.8, 1.0) if k in (0, 1, 7, 9) else 1.0) for k, x in enumerate(s)]
+            if opaque:
+                vals[7] = 0.0; vals[9] = 0.0
+            f.write(" ".join("%g" % x for x in vals) + "\n")
     with open(prefix + ".lgt", "w") as f:
         nl = int(rng.integers(1, 5))
         f.write("%d\n" % nl)
-        for _ in range(nl):
+        for li in range(nl):
             p = centre + rng.uniform(-0.9, 0.9, 3) * ext
             p[1] = centre[1] + rng.uniform(0.2, 0.95) * ext
+            if hard_lights and li == 0:
+                p[1] = lo[1]                      # in the floor's plane
+            elif hard_lights and li == 1:
+                p = np.array([lo[0], lo[1], hi[2]])  # the corner where floor, back wall and side wall meet
+            elif hard_lights and li == 2:
+                p = cc.copy()                     # inside the crowded cluster
             f.write("%s %s %s %g %g %g %g\n" % (fmt(p[0]), fmt(p[1]), fmt(p[2]), ext * ext * rng.uniform(50, 500),
                                                  rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1)))
     if seed % 6 == 0:  # a planar light under the ceiling: 16 rand() samples per shaded hit, drawn in the reference's pixel order

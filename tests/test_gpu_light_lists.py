@@ -66,3 +66,35 @@ def test_scenes_the_lists_do_not_apply_to_go_without():
             assert cnt["shadow_list_tickets"] == 0 and cnt["shadow_list_fallbacks"] == 0
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_random_opaque_scenes_with_lights_in_hard_places(tmp_path, seed):
+    """Generated scenes without transparent or reflective surfaces (tests/scenegen.py: a room of large triangles, boxes, a
+    crowded cluster, slivers), lights in the floor's plane, on a corner of the geometry, inside the cluster: the frame from
+    the lists equals the frame from the walks and the CPU oracle's (ids and raw colour bit for bit outside pow())."""
+    from oracle import oracle as O
+    from conftest import pow_free_pixels
+    from tests.scenegen import write_scene
+    os.chdir(ROOT)
+    prefix = write_scene(str(tmp_path), seed, 256, 192, opaque=True, hard_lights=True)
+    scene = rt.Scene(prefix)
+    r = rt.Renderer(0)
+    try:
+        on, con = frame(r, scene, 1)
+        off, coff = frame(r, scene, 0)
+    finally:
+        r.close()
+    assert np.array_equal(on["ids"], off["ids"])
+    assert np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32))
+    assert con["shadow_list_tickets"] + con["shadow_list_fallbacks"] > 0 and coff["shadow_list_tickets"] == 0
+    osc = O.OracleScene(prefix)
+    o = osc.render(shadow_cache=False, threads=1 if osc.npl else 4)
+    assert np.array_equal(on["ids"], o["ids"])
+    clean = o["taint"] == 0
+    exact = pow_free_pixels(scene, o["ids"]) & clean
+    assert np.array_equal(on["rgb"][exact].view(np.uint32), o["rgb"][exact].view(np.uint32))
+    fin = clean[..., None] & np.isfinite(o["rgb"])
+    rel = np.abs(on["rgb"][fin] - o["rgb"][fin]) / np.maximum(np.abs(o["rgb"][fin]), 1e-30)
+    assert rel.max() <= 1e-4
+    print("seed %d: %d tickets from the lists, %d walked" % (seed, con["shadow_list_tickets"], con["shadow_list_fallbacks"]))
