@@ -540,3 +540,61 @@ def test_fan_of_a_point_lights_shadow_rays(scale, offset, box):
         keep2 = fan_slabs_pass(T2, fma(T2["k1"], np.maximum(on1, on2), np.abs(T2["k2"])), lo, hi, light, smax)
         assert keep2[acc2].all()
         assert (~keep2).mean() > 0.3
+
+
+def fan_plane_behind(T, kc_max, lo, hi, light, smax):
+    """fan_plane_behind of rt_kernels.h, operation by operation in float32: does the record's plane surely lie behind every
+    shadow ray of the point light `light` that starts in the box lo..hi?"""
+    N, ac, an = T["N"], T["ac"], T["an"]
+    with np.errstate(all="ignore"):
+        c = (F(0.5) * (lo + hi)).astype(F)
+        h = fma(np.maximum(hi - c, c - lo), np.full_like(c, F(1.000001)), np.full_like(c, F(1e-30)))
+        rc = (light - c).astype(F)
+        det = fma(rc[:, 0], N[:, 0], fma(rc[:, 1], N[:, 1], rc[:, 2] * N[:, 2]))
+        dp = fma(-c[:, 0], N[:, 0], fma(-c[:, 1], N[:, 1], fma(-c[:, 2], N[:, 2], an)))
+        ob = (fma(np.abs(N[:, 0]), h[:, 0], fma(np.abs(N[:, 1]), h[:, 1], np.abs(N[:, 2]) * h[:, 2])) * F(1.001)).astype(F)
+        L = (np.sqrt(fma(ac[:, 0], ac[:, 0], fma(ac[:, 1], ac[:, 1], ac[:, 2] * ac[:, 2]))) * F(1.002)).astype(F)
+        sdp = np.where(np.signbit(det), -dp, dp).astype(F)
+        return (np.abs(det) - ob > F(1.5) * kc_max * smax) & (sdp + ob < F(-2.0) * L * kc_max)
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.05, 20.0), (10.0, -200.0), (1.0, 3000.0)])
+@pytest.mark.parametrize("box", ["point", "patch", "flat", "wide"])
+def test_plane_behind_the_fan_never_drops_a_hit(scale, offset, box):
+    """The other record-level test of the light lists (fan_plane_behind): a triangle the exact test accepts for a ray of the
+    fan, with whatever distance d >= 0, is never declared to lie behind the fan's rays; and triangles that do lie behind
+    (the same fans turned round) mostly are."""
+    rng = np.random.default_rng(int(scale * 1000) + int(offset) + 3 * len(box))
+    n = 300000
+    a, ab, ac, o, r0 = make_cases(rng, n, scale, offset, aim_edges)
+    d0 = np.linalg.norm((a - o).astype(np.float64), axis=1) + 1e-30
+    # the light on the ray: before, on (within a hair) and beyond the triangle
+    stretch = np.where(rng.random(n) < 0.3, 1.0 + rng.standard_normal(n) * 1e-6, 10.0 ** rng.uniform(-0.5, 0.5, n))
+    light = (o.astype(np.float64) + r0.astype(np.float64) * (d0 * stretch)[:, None]).astype(F)
+    rr = (light - o).astype(F)
+    s2 = rr[:, 0] * rr[:, 0] + rr[:, 1] * rr[:, 1] + rr[:, 2] * rr[:, 2]
+    with np.errstate(all="ignore"):
+        r = rr * (1.0 / np.sqrt(s2.astype(np.float64))).astype(F)[:, None]
+    dmax = np.sqrt(s2.astype(np.float64)).astype(F)
+    acc = exact_test(a, ab, ac, o, r)[0]
+    assert acc.mean() > 0.05
+    size = {"point": 0.0, "patch": 10.0 ** rng.uniform(-3, -1, (n, 1)), "flat": 10.0 ** rng.uniform(-3, -1, (n, 1)), "wide": 3.0}[box]
+    other = (o + (rng.standard_normal((n, 3)) * scale * size).astype(F)).astype(F)
+    if box == "flat":
+        ax = rng.integers(0, 3, n)
+        other[np.arange(n), ax] = o[np.arange(n), ax]
+    lo, hi = np.minimum(o, other), np.maximum(o, other)
+    T = preprocess(a, ab, ac)
+    _, on1, _ = ray_side(o, r)
+    _, on2, _ = ray_side(other, r)
+    kc_max = fma(T["k1"], np.maximum(on1, on2), np.abs(T["k2"]))
+    ro = (light - other).astype(np.float64)
+    smax = (np.maximum(dmax, np.sqrt((ro * ro).sum(1)).astype(F)) * F(1.00001)).astype(F)
+    behind = fan_plane_behind(T, kc_max, lo, hi, light, smax)
+    assert not behind[acc].any(), "a triangle a ray of the fan hits was declared to lie behind the fan"
+    if box in ("point", "patch") and offset == 0.0:
+        # the rays turned round (from the origin away from the triangle, towards a light on the other side): the plane is behind
+        light2 = (o.astype(np.float64) - r0.astype(np.float64) * (d0 * 2.0)[:, None]).astype(F)
+        ro2 = (light2 - other).astype(np.float64)
+        smax2 = (np.sqrt(np.maximum((ro2 * ro2).sum(1), ((light2 - o).astype(np.float64) ** 2).sum(1))).astype(F) * F(1.00001)).astype(F)
+        assert fan_plane_behind(T, kc_max, lo, hi, light2, smax2).mean() > 0.5
