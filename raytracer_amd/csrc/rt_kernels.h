@@ -2044,6 +2044,191 @@ RT_D void slot_light(const ShadeP &sp, int slot, int rand_rank, f3 &pos, float &
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shadow queries from the light lists (rt_lightlists.h; LightListsP), for the 64 hit points of a wavefront that look at one
+// point light.  Every walking lane (alive) finds its texel on the cube around the light; the lists of the texels the
+// wavefront covers hold every triangle the exact test can accept for any of its rays.  First the references: the texels'
+// lists are read 64 positions per pass and the triangles the wavefront takes (each once: at the first texel of its box
+// that the triangle's rectangle covers) are collected in LDS; then the collected triangles, 64 per pass: one lane per
+// triangle gathers its record and culls it for the whole fan (fan_plane_behind, fan_slabs_pass), what is left goes
+// through LDS to the test every lane runs.  A ray none of these triangles blocks is lit (hit_id stays -1); a ray one of
+// them blocks (hit_id: the triangle) is in shadow if lists_verify agrees.  false: the wavefront does not fit the lists
+// (a hit point outside the face's window or off the face, an origin beyond the norm the lists were built for, its box of
+// texels too large even at level max_level); nothing has been decided then.
+// The shadow test of one record for all lanes (the filter decides what it can prove, tri_test the rest, voxelize.c:700-711);
+// true if some lane passed the first slab.  For scenes without a transparent triangle: a hit counts if it blocks.
+RT_D bool lists_test(const GridP &g, const float *R, f3 a, f3 r, f3 pm, float kc, int cur, float dmax, int &hit_id, bool &open) {
+  const RecA A = rec_a(R);
+  PlTest t;
+  const bool p1 = pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
+  if (wave_any(p1)) {
+    asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into the per-lane one
+    int verdict = 0;
+    float kt = 0.0f;
+    bool s3 = false;
+    if (p1) verdict = shadow_verdict(R, A, t, a, r, pm, kc, g.lmax, dmax, kt, s3);
+    if (verdict != 0) {
+      const int id = rec_id(R);
+      if (id == cur) {
+        verdict = 0;
+      } else if (verdict == 1) {
+        float d, u, v;
+        verdict = (exact_test(g, id, a, r, d, u, v) && d > 0.00001f && d < dmax) ? 3 : 0;
+      }
+      if (verdict == 3) { hit_id = id; open = false; }
+    }
+    return true;
+  }
+  return false;
+}
+RT_D bool lists_lookup(const GridP &g, const LightListsP &ll, int light_i, const Fan &fan, bool alive, f3 a, f3 r, f3 pm, float onorm, int current,
+                       float dmax, float *slice, int lane, int max_level, int &hit_id, uint32_t (&diag)[3]) {
+  const unsigned long long walking = __ballot(alive);
+  const int first = __ffsll(walking) - 1;
+  // the face of the first walking lane's hit point, for all lanes: faces overlap (coordinates up to kLLFaceExt), so a
+  // tile across a seam of the cube is still looked up on one face
+  const f3 d = sub3(a, fan.L);
+  const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
+  const int ax_own = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
+  const int ax = __builtin_amdgcn_readlane(ax_own, first);
+  const float dw = ax == 0 ? d.x : ax == 1 ? d.y : d.z;
+  const float du = ax == 0 ? d.y : d.x, dv = ax == 2 ? d.y : d.z;
+  const bool neg = lane_bcast(dw, first) < 0.0f;
+  const float aw = __builtin_fabsf(dw);
+  const float p = du / aw, q = dv / aw;
+  const bool onface = (dw < 0.0f) == neg && __builtin_fabsf(p) <= kLLFaceExt && __builtin_fabsf(q) <= kLLFaceExt;  // (a NaN: false)
+  const int face0 = ax * 2 + (neg ? 1 : 0);
+  LLFaceD F = ll.faces[(light_i * 6 + face0) * 2];
+  // window 0 if every hit point lies in it, else window 1 (the whole face)
+  if (F.on == 0u || __ballot(alive && !(p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1)) != 0) F = ll.faces[(light_i * 6 + face0) * 2 + 1];
+  const bool fits = !alive || (onface && p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1 && onorm <= ll.olim);
+  int tu = (int)((p - F.p0) * F.sp), tv = (int)((q - F.q0) * F.sq);
+  tu = tu < 0 ? 0 : tu > ll.R - 1 ? ll.R - 1 : tu;
+  tv = tv < 0 ? 0 : tv > ll.R - 1 ? ll.R - 1 : tv;
+  if (F.on == 0u || __ballot(!fits) != 0) return false;
+  int U0 = -(int)wave_max(alive ? -(float)tu : -1e9f), U1 = (int)wave_max(alive ? (float)tu : -1.0f);
+  int V0 = -(int)wave_max(alive ? -(float)tv : -1e9f), V1 = (int)wave_max(alive ? (float)tv : -1.0f);
+  // the finest level at which the wavefront's box of texels is small (a texel of level l is 2^l x 2^l of level 0's)
+  int level = 0;
+  while (level < max_level && ((U1 >> level) - (U0 >> level) + 1) * ((V1 >> level) - (V0 >> level) + 1) > RT_LL_TEXELS) level++;
+  U0 >>= level; U1 >>= level; V0 >>= level; V1 >>= level;
+  const int nw = U1 - U0 + 1, ntex = nw * (V1 - V0 + 1), Rl = ll.R >> level;
+  if (ntex > (level < ll.levels - 1 ? RT_LL_TEXELS : 64)) return false;
+  uint32_t off = 0u, cnt = 0u;
+  if (lane < ntex) {
+    const uint32_t t = ll_level_base(ll.texels0, level) + (F.base >> (2 * level)) + (uint32_t)((V0 + lane / nw) * Rl + U0 + lane % nw);
+    off = ll.offsets[t]; cnt = ll.offsets[t + 1] - off;
+  }
+  const float onorm_all = wave_max(alive ? onorm : 0.0f);
+  diag[0] = (uint32_t)(level * 1000 + ntex);
+  bool open = alive, go = true;
+  int tx = U0, ty = V0;
+  constexpr int kSlots = 32;                                   // records of the slice for a pass's survivors ...
+  constexpr int kIds = kSliceFloats - kSlots * kRecFloats;     // ... and the rest for the collected triangles
+  static_assert(kIds >= 128, "room for two passes' references");
+  int *ids = reinterpret_cast<int *>(slice + kSlots * kRecFloats);
+  int nids = 0;
+  int j = 0;
+  uint32_t k0 = 0u;
+  for (;;) {
+    while (j < ntex && nids <= kIds - 64) {
+      const uint32_t off_j = (uint32_t)__builtin_amdgcn_readlane((int)off, j), cnt_j = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+      if (k0 < cnt_j) {
+        const uint32_t at = k0 + (uint32_t)lane;
+        bool own = false;
+        int id = 0;
+        if (at < cnt_j) {
+          const LLRef ref = ll.refs[off_j + at];
+          const int ra0 = (int)(ref.rect & 255u), rb0 = (int)((ref.rect >> 16) & 255u);
+          own = tx == (ra0 > U0 ? ra0 : U0) && ty == (rb0 > V0 ? rb0 : V0);
+          id = ref.tri;
+        }
+        const unsigned long long m = __ballot(own);
+        if (own) ids[nids + __popcll(m & lanes_below(lane))] = id;
+        nids += __popcll(m);
+        diag[1] += (uint32_t)__popcll(m);
+        k0 += 64u;
+      }
+      if (k0 >= cnt_j) {
+        j++; k0 = 0u;
+        if (++tx > U1) { tx = U0; ty++; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (nids == 0) break;
+    for (int b0 = 0; b0 < nids && go; b0 += 64) {
+      bool pass = false;
+      const v4f *R = nullptr;
+      if (b0 + lane < nids) {
+        R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)ids[b0 + lane]);
+        const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+        RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
+        const float kc_max = __builtin_fmaf(r0.w, onorm_all, r2.w);
+        pass = !fan_plane_behind(A, r4.z, kc_max, fan) &&
+               fan_slabs_pass(A, mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), kc_max, r0.w, r2.w, fan);
+      }
+      unsigned long long todo = __ballot(pass);
+      while (todo != 0 && go) {
+        const int before = __popcll(todo & lanes_below(lane));
+        const bool mine = ((todo >> lane) & 1ull) != 0 && before < kSlots;
+        if (mine) {
+          v4f *D = reinterpret_cast<v4f *>(slice + before * kRecFloats);
+          const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+          D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4;
+        }
+        const unsigned long long placed = __ballot(mine);
+        todo &= ~placed;
+        __builtin_amdgcn_wave_barrier();
+        const int n = __popcll(placed);
+        diag[2] += (uint32_t)n;
+        for (int q2 = 0; q2 < n && go; q2++) {
+          const float *Rj = slice + q2 * kRecFloats;
+          const float kc = open ? __builtin_fmaf(Rj[3], onorm, Rj[11]) : -INFINITY;
+          if (lists_test(g, Rj, a, r, pm, kc, current, dmax, hit_id, open)) go = __ballot(open) != 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    nids = 0;
+    if (!go || j >= ntex) break;
+  }
+  return true;
+}
+// The candidate blockers against the walks: a lane's blocker counts if its own walk (the reference's accumulated-sum DDA,
+// stepped without looking at any list) passes a cell of the triangle's voxel box, i.e. a cell that lists it: the reference's
+// scan finds a blocker there at the latest (voxelize.c:615-738 stops at the first).  start(v, vi, vj, vk) gives a lane's
+// walk standing in the voxel of its hit point, and that voxel.  false: some lane's blocker is not on its walk (nothing is
+// decided then).
+template <typename S>
+RT_D bool lists_verify(const LightListsP &ll, bool alive, int hit_id, f3 r, S &&start) {
+  bool need = alive && hit_id >= 0, failed = false;
+  if (__ballot(need) != 0) {
+    int lo0 = 0, lo1 = 0, lo2 = 0, hi0 = -1, hi1 = -1, hi2 = -1, vi = 0, vj = 0, vk = 0;
+    Walk v;
+    v.tx = v.ty = v.tz = v.dtx = v.dty = v.dtz = 0.0f; v.cell = 0; v.nx = v.ny = v.nz = 0;
+    if (need) {
+      const int32_t *bx = ll.tri_box + 6 * (size_t)hit_id;
+      lo0 = bx[0]; lo1 = bx[1]; lo2 = bx[2]; hi0 = bx[3]; hi1 = bx[4]; hi2 = bx[5];
+      start(v, vi, vj, vk);
+    }
+    const int si = r.x > 0.0f ? 1 : -1, sj = r.y > 0.0f ? 1 : -1, sk = r.z > 0.0f ? 1 : -1;
+    for (;;) {
+      if (need && vi >= lo0 && vi <= hi0 && vj >= lo1 && vj <= hi1 && vk >= lo2 && vk <= hi2) need = false;
+      if (__ballot(need) == 0) break;
+      if (need) {  // walk_step, with the voxel's indices instead of the cell's
+        const float xn = v.tx + v.dtx, yn = v.ty + v.dty, zn = v.tz + v.dtz;
+        const bool xy = xn < yn;
+        const bool sx = xy & (xn < zn), sy = !xy & (yn < zn);
+        v.tx = sx ? xn : v.tx; v.ty = sy ? yn : v.ty; v.tz = (sx | sy) ? v.tz : zn;
+        v.nx -= sx ? 1 : 0; v.ny -= sy ? 1 : 0; v.nz -= (sx | sy) ? 0 : 1;
+        vi += sx ? si : 0; vj += sy ? sj : 0; vk += (sx | sy) ? 0 : sk;
+        if ((v.nx | v.ny | v.nz) < 0) { need = false; failed = true; }
+      }
+    }
+  }
+  return __ballot(failed) == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Shadow walk (voxelize.c:615-738), any-hit, persistent wavefront kernel with the same per-cell
 // organisation as k_nearest.  Work item = (shadow slot, shaded hit) in slot-major order, so the 64
 // lanes of a ticket are neighbouring hit points looking at the same light.  Result per item: the
@@ -2217,168 +2402,25 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
     };
     if (LL) {
       ph.end<0>();
-      // The light's lists instead of the walk.  The ticket's hit points look at one point light (ticket_fan); every
-      // walking lane finds its texel on the cube around the light; the lists of the texels the ticket covers hold every
-      // triangle the exact test can accept for any of its rays (rt_lightlists.h).  One lane per reference: the triangle's
-      // record is culled for the whole fan (plane behind the rays, fan_slabs_pass), what is left goes through LDS to the
-      // test every lane runs.  A ray none of these triangles blocks is lit.  A ray one of them blocks is in shadow if its
-      // own walk passes a cell of the triangle's voxel box, i.e. a cell that lists it: the reference's scan finds a
-      // blocker there at the latest (voxelize.c:615-738 stops at the first); the walk's cells are stepped through without
-      // looking at their lists.  Where that fails, or the ticket does not fit the lists (rays on several faces, outside the
-      // face's window, origins beyond the norm the lists were built for, too many texels), the ticket takes the walk below.
+      // The light's lists instead of the walk (lists_lookup, lists_verify), for a ticket whose walks all end at one point
+      // light (ticket_fan).  Where they do not apply or do not agree, the ticket takes the walk below, from its untouched state.
       const LightListsP ll = fresh_arg<LightListsP>(offsetof(ShadowArgs, ll));
       const unsigned long long walking = __ballot(alive);
       if (ll.on && ticket_fan.on && walking != 0) {
         nListFell++;
-        const int first = __ffsll(walking) - 1;
-        const int light_i = __builtin_amdgcn_readlane(slot, first);
-        // the face of the first walking lane's hit point, for all lanes: faces overlap (coordinates up to kLLFaceExt), so a
-        // tile across a seam of the cube is still looked up on one face
-        const f3 d = sub3(a, ticket_fan.L);
-        const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
-        const int ax_own = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
-        const int ax = __builtin_amdgcn_readlane(ax_own, first);
-        const float dw = ax == 0 ? d.x : ax == 1 ? d.y : d.z;
-        const float du = ax == 0 ? d.y : d.x, dv = ax == 2 ? d.y : d.z;
-        const bool neg = lane_bcast(dw, first) < 0.0f;
-        const float aw = __builtin_fabsf(dw);
-        const float p = du / aw, q = dv / aw;
-        const bool onface = (dw < 0.0f) == neg && __builtin_fabsf(p) <= kLLFaceExt && __builtin_fabsf(q) <= kLLFaceExt;  // (a NaN: false)
-        const int face0 = ax * 2 + (neg ? 1 : 0);
-        LLFaceD F = ll.faces[(light_i * 6 + face0) * 2];
-        // window 0 if every hit point lies in it, else window 1 (the whole face)
-        if (F.on == 0u || __ballot(alive && !(p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1)) != 0) F = ll.faces[(light_i * 6 + face0) * 2 + 1];
-        const bool fits = !alive || (onface && p >= F.p0 && p <= F.p1 && q >= F.q0 && q <= F.q1 && onorm <= ll.olim);
-        int tu = (int)((p - F.p0) * F.sp), tv = (int)((q - F.q0) * F.sq);
-        tu = tu < 0 ? 0 : tu > ll.R - 1 ? ll.R - 1 : tu;
-        tv = tv < 0 ? 0 : tv > ll.R - 1 ? ll.R - 1 : tv;
-        if (F.on != 0u && __ballot(!fits) == 0) {
-          int U0 = -(int)wave_max(alive ? -(float)tu : -1e9f), U1 = (int)wave_max(alive ? (float)tu : -1.0f);
-          int V0 = -(int)wave_max(alive ? -(float)tv : -1e9f), V1 = (int)wave_max(alive ? (float)tv : -1.0f);
-          // the finest level at which the ticket's box of texels is small (a texel of level l is 2^l x 2^l of level 0's)
-          int level = 0;
-          while (level + 1 < ll.levels && ((U1 >> level) - (U0 >> level) + 1) * ((V1 >> level) - (V0 >> level) + 1) > RT_LL_TEXELS) level++;
-          U0 >>= level; U1 >>= level; V0 >>= level; V1 >>= level;
-          const int nw = U1 - U0 + 1, ntex = nw * (V1 - V0 + 1), Rl = ll.R >> level;
-          if (ntex <= 64) {
-            uint32_t off = 0u, cnt = 0u;
-            if (lane < ntex) {
-              const uint32_t t = ll_level_base(ll.texels0, level) + (F.base >> (2 * level)) + (uint32_t)((V0 + lane / nw) * Rl + U0 + lane % nw);
-              off = ll.offsets[t]; cnt = ll.offsets[t + 1] - off;
-            }
-            const float onorm_all = wave_max(alive ? onorm : 0.0f);
-            RT_TICKET(tl.visits = (uint32_t)(level * 1000 + ntex);)  // (diagnostic build: what a ticket settled from the lists looked at)
-            int hit_id = -1;
-            bool open = alive, go = true;
-            int tx = U0, ty = V0;
-            // First the references: those the ticket takes (each triangle once) are collected in LDS, one texel's list
-            // after the other, 64 list positions per pass; then the collected triangles' records, 64 per pass (and in
-            // between whenever the collection is full).
-            constexpr int kSlots = 32;                                   // records of the slice for a pass's survivors ...
-            constexpr int kIds = kSliceFloats - kSlots * kRecFloats;     // ... and the rest for the collected triangles
-            static_assert(kIds >= 128, "room for two passes' references");
-            int *ids = reinterpret_cast<int *>(slice + kSlots * kRecFloats);
-            int nids = 0;
-            int j = 0;
-            uint32_t k0 = 0u;
-            for (;;) {
-              while (j < ntex && nids <= kIds - 64) {
-                const uint32_t off_j = (uint32_t)__builtin_amdgcn_readlane((int)off, j), cnt_j = (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
-                if (k0 < cnt_j) {
-                  const uint32_t at = k0 + (uint32_t)lane;
-                  bool own = false;
-                  int id = 0;
-                  if (at < cnt_j) {
-                    const LLRef ref = ll.refs[off_j + at];
-                    const int ra0 = (int)(ref.rect & 255u), rb0 = (int)((ref.rect >> 16) & 255u);
-                    // (a triangle whose rectangle covers several of the ticket's texels is taken at the first of them)
-                    own = tx == (ra0 > U0 ? ra0 : U0) && ty == (rb0 > V0 ? rb0 : V0);
-                    id = ref.tri;
-                  }
-                  const unsigned long long m = __ballot(own);
-                  if (own) ids[nids + __popcll(m & lanes_below(lane))] = id;
-                  nids += __popcll(m);
-                  RT_TICKET(tl.batches += (uint32_t)__popcll(m);)
-                  k0 += 64u;
-                }
-                if (k0 >= cnt_j) {
-                  j++; k0 = 0u;
-                  if (++tx > U1) { tx = U0; ty++; }
-                }
-              }
-              __builtin_amdgcn_wave_barrier();
-              if (nids == 0) break;
-              for (int b0 = 0; b0 < nids && go; b0 += 64) {
-                bool pass = false;
-                const v4f *R = nullptr;
-                if (b0 + lane < nids) {
-                  R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)ids[b0 + lane]);
-                  const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
-                  RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
-                  const float kc_max = __builtin_fmaf(r0.w, onorm_all, r2.w);
-                  pass = !fan_plane_behind(A, r4.z, kc_max, ticket_fan) &&
-                         fan_slabs_pass(A, mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), kc_max, r0.w, r2.w, ticket_fan);
-                }
-                unsigned long long todo = __ballot(pass);
-                while (todo != 0 && go) {
-                  const int before = __popcll(todo & lanes_below(lane));
-                  const bool mine = ((todo >> lane) & 1ull) != 0 && before < kSlots;
-                  if (mine) {
-                    v4f *D = reinterpret_cast<v4f *>(slice + before * kRecFloats);
-                    const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
-                    D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4;
-                  }
-                  const unsigned long long placed = __ballot(mine);
-                  todo &= ~placed;
-                  __builtin_amdgcn_wave_barrier();
-                  const int n = __popcll(placed);
-                  RT_TICKET(tl.tests += (uint32_t)n;)
-                  for (int q2 = 0; q2 < n && go; q2++) {
-                    const float *Rj = slice + q2 * kRecFloats;
-                    const float kc = open ? __builtin_fmaf(Rj[3], onorm, Rj[11]) : -INFINITY;
-                    test(Rj, a, r, pm, kc, current, dmax, [&](int verdict, float) {
-                      if (verdict == 3) { hit_id = rec_id(Rj); open = false; }
-                      go = __ballot(open) != 0;
-                    });
-                  }
-                  __builtin_amdgcn_wave_barrier();
-                }
-              }
-              nids = 0;
-              if (!go || j >= ntex) break;
-            }
-            // the candidate blockers against the walks
-            bool need = alive && hit_id >= 0, failed = false;
-            if (__ballot(need) != 0) {
-              int lo0 = 0, lo1 = 0, lo2 = 0, hi0 = -1, hi1 = -1, hi2 = -1, vi = 0, vj = 0, vk = 0;
-              if (need) {
-                const int32_t *bx = ll.tri_box + 6 * (size_t)hit_id;
-                lo0 = bx[0]; lo1 = bx[1]; lo2 = bx[2]; hi0 = bx[3]; hi1 = bx[4]; hi2 = bx[5];
-                (void)voxel_of(g, a, vi, vj, vk);  // (the walk still stands in its first cell, the hit point's voxel)
-              }
-              Walk v = w;
-              const int si = r.x > 0.0f ? 1 : -1, sj = r.y > 0.0f ? 1 : -1, sk = r.z > 0.0f ? 1 : -1;
-              for (;;) {
-                if (need && vi >= lo0 && vi <= hi0 && vj >= lo1 && vj <= hi1 && vk >= lo2 && vk <= hi2) need = false;
-                if (__ballot(need) == 0) break;
-                if (need) {  // walk_step, with the voxel's indices instead of the cell's
-                  const float xn = v.tx + v.dtx, yn = v.ty + v.dty, zn = v.tz + v.dtz;
-                  const bool xy = xn < yn;
-                  const bool sx = xy & (xn < zn), sy = !xy & (yn < zn);
-                  v.tx = sx ? xn : v.tx; v.ty = sy ? yn : v.ty; v.tz = (sx | sy) ? v.tz : zn;
-                  v.nx -= sx ? 1 : 0; v.ny -= sy ? 1 : 0; v.nz -= (sx | sy) ? 0 : 1;
-                  vi += sx ? si : 0; vj += sy ? sj : 0; vk += (sx | sy) ? 0 : sk;
-                  if ((v.nx | v.ny | v.nz) < 0) { need = false; failed = true; }
-                }
-              }
-            }
-            if (__ballot(failed) == 0) {  // the ticket is settled
-              if (alive && hit_id >= 0) result = -1.0f;
-              alive = false;
-              nListed++; nListFell--;
-            }
-          }
+        const int light_i = __builtin_amdgcn_readlane(slot, __ffsll(walking) - 1);
+        int hit_id = -1;
+        uint32_t diag[3] = {0u, 0u, 0u};
+        if (lists_lookup(g, ll, light_i, ticket_fan, alive, a, r, pm, onorm, current, dmax, slice, lane, ll.levels - 1, hit_id, diag) &&
+            lists_verify(ll, alive, hit_id, r, [&](Walk &v, int &vi, int &vj, int &vk) {
+              v = w;
+              (void)voxel_of(g, a, vi, vj, vk);  // (the walk still stands in its first cell, the hit point's voxel)
+            })) {
+          if (alive && hit_id >= 0) result = -1.0f;
+          alive = false;
+          nListed++; nListFell--;
         }
+        RT_TICKET(tl.visits = diag[0]; tl.batches = diag[1]; tl.tests = diag[2];)  // (diagnostic build: what the ticket looked at)
       }
       if (__ballot(alive) != 0) {  // the ticket walks after all: what the set-up left out
         const GridP g = fresh_arg<GridP>(offsetof(ShadowArgs, g));
