@@ -2242,6 +2242,7 @@ struct ShadowArgs {
   GridP g; ShadeP sp; const SOrigin *sorg; const int32_t *rand_rank; float *ts_out; long long ts_stride; Ctl *ctl;
   int level, node_base; const uint32_t *order;
   LightListsP ll;
+  const uint32_t *ticket_list;  // null, or (LL instance, queue length a multiple of 64): [0] how many tickets, then their numbers: only these are done
 };
 // LL: tickets whose walks all end at one point light are answered from that light's lists where they can be (below)
 template <bool COUNT, bool RECTEST, bool ENDS, bool LL = false>
@@ -2269,11 +2270,13 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
   Phases ph;
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
-  Tickets tickets((unsigned long long)total);
+  const uint32_t *__restrict__ ticket_list = LL ? args.ticket_list : nullptr;
+  Tickets tickets(ticket_list ? 64ull * ticket_list[0] : (unsigned long long)total);
   uint32_t nListed = 0, nListFell = 0;  // tickets answered from the light lists / tried and walked after all
   for (;;) {
     uint32_t base;
     if (!tickets.take(ticket_counters(fresh_arg<Ctl *>(offsetof(ShadowArgs, ctl)), 1, fresh_arg<int>(offsetof(ShadowArgs, level))), lane, base)) break;
+    if (LL && ticket_list) base = 64u * fresh_arg<const uint32_t *>(offsetof(ShadowArgs, ticket_list))[1 + (base >> 6)];
     RT_TICKET(TicketLog tl; tl.begin();)
     const long long item = (long long)base + lane;
     bool alive = false;
@@ -2580,6 +2583,114 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
       atomicAdd(&ctl->stat[kShadVisits], nVisit); atomicAdd(&ctl->stat[kShadBatches], nBatch); atomicAdd(&ctl->stat[kShadCulled], nCull);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shadow queries from the light lists alone (scenes without transparent triangles, point lights only, one recursion
+// level): what k_shadow<..., LL> does inside its ticket loop, without the walk's code and state around it.  A ticket is 64
+// consecutive shaded hits (a tile's hit points) and goes through all lights in turn: the hit points, their normals,
+// voxels and bounding box are fetched and worked out once for all lights.  Only the narrow cases are settled here (the
+// tile's hit points cover few texels at one of the two finest levels): their cost is even, so the wavefronts finish
+// together.  A (ticket, light) that is wide, or that the lists cannot settle, is appended to `deferred` (deferred[0]: how
+// many; entries light * (n / 64) + ticket: k_shadow's own ticket numbers) and left to k_shadow, where every such pair is a
+// ticket of its own.
+#ifndef RT_WAVES_LISTS
+#define RT_WAVES_LISTS 6
+#endif
+struct ListsArgs {
+  GridP g; ShadeP sp; const SOrigin *sorg; float *ts_out; long long ts_stride; Ctl *ctl; int node_base; LightListsP ll;
+  uint32_t *deferred;
+};
+__global__ void __launch_bounds__(256, RT_WAVES_LISTS) k_shadow_lists(ListsArgs args) {
+  __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
+  float *slice = lds_batches[threadIdx.x >> 6];
+  const int lane = lane_id();
+  const GridP &g = args.g;
+  const LightListsP &ll = args.ll;
+  const int n = queue_len(args.ctl, 0);
+  uint32_t nListed = 0, nDeferred = 0;
+  Tickets tickets((unsigned long long)n);
+  for (;;) {
+    uint32_t base;
+    if (!tickets.take(ticket_counters(args.ctl, 1, 1), lane, base)) break;  // (the counters of level 1's shadow walk: there is no level 1)
+    const int node = (int)base + lane;
+    int current = -1;
+    f3 a = mk3(0.0f, 0.0f, 0.0f), nrm = mk3(0.0f, 0.0f, 0.0f);
+    if (node < n) {
+      const SOrigin nd = args.sorg[args.node_base + node];
+      current = nd.tri;
+      a = ld3(nd.p);
+    }
+    const bool has = current >= 0;
+    if (__ballot(has) == 0) continue;
+    if (has) nrm = ld3(args.sp.tri_aux + 4 * current);
+    int ai[3] = {0, 0, 0};
+    const bool a_in = has && voxel_of(g, a, ai[0], ai[1], ai[2]);
+    // the box of the ticket's hit points, for the fans of all lights (make_fan; a NaN among them: no fan, the walk)
+    const bool nan_any = __ballot(has && (a.x != a.x || a.y != a.y || a.z != a.z)) != 0;
+    const f3 blo = mk3(-wave_max(has ? -a.x : -INFINITY), -wave_max(has ? -a.y : -INFINITY), -wave_max(has ? -a.z : -INFINITY));
+    const f3 bhi = mk3(wave_max(has ? a.x : -INFINITY), wave_max(has ? a.y : -INFINITY), wave_max(has ? a.z : -INFINITY));
+    const f3 bc = mk3(0.5f * (blo.x + bhi.x), 0.5f * (blo.y + bhi.y), 0.5f * (blo.z + bhi.z));
+    const f3 bh = mk3(__builtin_fmaf(__builtin_fmaxf(bhi.x - bc.x, bc.x - blo.x), 1.000001f, 1e-30f),
+                      __builtin_fmaf(__builtin_fmaxf(bhi.y - bc.y, bc.y - blo.y), 1.000001f, 1e-30f),
+                      __builtin_fmaf(__builtin_fmaxf(bhi.z - bc.z, bc.z - blo.z), 1.000001f, 1e-30f));
+    for (int light_i = 0; light_i < args.sp.nl; light_i++) {
+      const f3 b = ld3(args.sp.lights[light_i].p);
+      const f3 r = ray3(a, b);
+      float result = 1.0f, dmax = 0.0f;
+      bool alive = false;
+      int bi[3] = {0, 0, 0};
+      if (has) {
+        if (dot3(r, nrm) <= 0.0f) result = -1.0f;  // voxelize.c:640-644 (no triangle is transparent here)
+        else {
+          dmax = dist3(a, b);
+          // a point outside the grid: the reference reports an error and treats the light as visible (voxelize.c:661-670)
+          alive = a_in && voxel_of(g, b, bi[0], bi[1], bi[2]);
+        }
+      }
+      bool settled = true;
+      if (__ballot(alive) != 0) {
+        settled = false;
+        f3 pm; float onorm, odr;
+        pl_ray(a, r, pm, onorm, odr);
+        Fan fan;
+        {
+          const f3 rc = sub3(b, bc);
+          const f3 mc = mk3(__builtin_fmaf(bc.y, rc.z, -(bc.z * rc.y)), __builtin_fmaf(bc.z, rc.x, -(bc.x * rc.z)), __builtin_fmaf(bc.x, rc.y, -(bc.y * rc.x)));
+          fan.on = !nan_any;
+          fan.c = lane_bcast3(bc, 0); fan.h = lane_bcast3(bh, 0); fan.rc = lane_bcast3(rc, 0); fan.mc = lane_bcast3(mc, 0); fan.L = lane_bcast3(b, 0);
+          fan.smax = lane_bcast(wave_max(alive ? dmax : 0.0f) * 1.00001f, 0);
+          fan.hsum = lane_bcast(bh.x + bh.y + bh.z, 0);
+          fan.lnorm = lane_bcast(__builtin_fabsf(b.x) + __builtin_fabsf(b.y) + __builtin_fabsf(b.z), 0);
+        }
+        int hit_id = -1;
+        uint32_t diag[3] = {0u, 0u, 0u};
+        if (fan.on && lists_lookup(g, ll, light_i, fan, alive, a, r, pm, onorm, current, dmax, slice, lane, ll.levels > 1 ? 1 : 0, hit_id, diag) &&
+            lists_verify(ll, alive, hit_id, r, [&](Walk &v, int &vi, int &vj, int &vk) {
+              int lo[3], hi[3];
+#pragma unroll
+              for (int c = 0; c < 3; c++) { lo[c] = ai[c] < bi[c] ? ai[c] : bi[c]; hi[c] = ai[c] < bi[c] ? bi[c] : ai[c]; }
+              walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, true, v);
+              vi = ai[0]; vj = ai[1]; vk = ai[2];
+            })) {
+          if (alive && hit_id >= 0) result = -1.0f;
+          settled = true;
+          nListed++;
+        }
+      }
+      if (settled) {
+        // slot-major, like k_shadow: one 256-byte line per ticket and light
+        if (has) args.ts_out[(long long)light_i * args.ts_stride + args.node_base + node] = result < 0.0f ? -1.0f : 1.0f;
+      } else {
+        nDeferred++;
+        if (lane == 0) {
+          const uint32_t at = atomicAdd(args.deferred, 1u);
+          args.deferred[1 + at] = (uint32_t)light_i * (uint32_t)(n >> 6) + (base >> 6);
+        }
+      }
+    }
+  }
+  if (lane == 0 && nListed != 0) atomicAdd(&args.ctl->stat[kShadListTickets], (unsigned long long)nListed);
 }
 
 RT_D void mm_fold(float *mn, float *mx, const float *omn, const float *omx) {

@@ -159,6 +159,8 @@ struct rtgpu_ctx {
   LLRef *d_ll_refs = nullptr;
   LLFaceD *d_ll_faces = nullptr;
   size_t cap_ll_texels = 0, cap_ll_refs = 0, cap_ll_faces = 0;
+  uint32_t *d_ll_deferred = nullptr;  // (ticket, light) pairs k_shadow_lists leaves to k_shadow (one of the chunk's queues)
+  bool opt_ll_kernel = true;  // option "light_list_kernel": the lists' own kernel where it applies (else inside k_shadow only)
   // timing
   std::vector<TimedSpan> spans;
   rtgpu_timings timings = {};
@@ -303,6 +305,8 @@ int plan_queues(rtgpu_ctx *c, size_t tiles, F &&give) {
   const size_t nrank = c->npl > 0 ? total : 1;
   if ((rc = give((void **)&c->d_rank, sizeof(int32_t) * nrank)) || (rc = give((void **)&c->d_size, sizeof(int32_t) * nrank))) return rc;
   if ((rc = give((void **)&c->d_order, sizeof(uint32_t) * (c->levels > 1 || c->opt_order > 1 ? total : 1)))) return rc;
+  // the (ticket, light) pairs k_shadow_lists leaves to k_shadow: at most every pair of the chunk
+  if ((rc = give((void **)&c->d_ll_deferred, sizeof(uint32_t) * (c->levels == 1 && c->npl == 0 ? tiles * (size_t)(c->nl > 0 ? c->nl : 0) + 1 : 1)))) return rc;
   return RTGPU_OK;
 }
 
@@ -340,7 +344,7 @@ int ensure_chunk(rtgpu_ctx *c, size_t tiles) {
 // The chunk queues of a context, as a value: rtgpu_render_static puts the carved ones in and the context's own back.
 struct QueueSet {
   size_t chunk_tiles_cap, cap[kMaxLevels], base[kMaxLevels], total_nodes;
-  Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; SOrigin *d_sorg; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size; uint32_t *d_order;
+  Ray *d_rays[kMaxLevels]; Hit *d_hits; Node *d_nodes; SOrigin *d_sorg; float *d_colors, *d_ts, *d_partial; int32_t *d_rank, *d_size; uint32_t *d_order, *d_ll_deferred;
 };
 QueueSet take_queues(rtgpu_ctx *c) {
   QueueSet q;
@@ -348,6 +352,7 @@ QueueSet take_queues(rtgpu_ctx *c) {
   for (int L = 0; L < kMaxLevels; L++) { q.cap[L] = c->cap[L]; q.base[L] = c->base[L]; q.d_rays[L] = c->d_rays[L]; c->d_rays[L] = nullptr; }
   q.d_hits = c->d_hits; q.d_nodes = c->d_nodes; q.d_sorg = c->d_sorg; q.d_colors = c->d_colors; q.d_ts = c->d_ts; q.d_partial = c->d_partial;
   q.d_rank = c->d_rank; q.d_size = c->d_size; q.d_order = c->d_order; c->d_order = nullptr;
+  q.d_ll_deferred = c->d_ll_deferred; c->d_ll_deferred = nullptr;
   c->d_hits = nullptr; c->d_nodes = nullptr; c->d_sorg = nullptr; c->d_colors = c->d_ts = c->d_partial = nullptr; c->d_rank = c->d_size = nullptr;
   return q;
 }
@@ -355,7 +360,7 @@ void put_queues(rtgpu_ctx *c, const QueueSet &q) {
   c->chunk_tiles_cap = q.chunk_tiles_cap; c->total_nodes = q.total_nodes;
   for (int L = 0; L < kMaxLevels; L++) { c->cap[L] = q.cap[L]; c->base[L] = q.base[L]; c->d_rays[L] = q.d_rays[L]; }
   c->d_hits = q.d_hits; c->d_nodes = q.d_nodes; c->d_sorg = q.d_sorg; c->d_colors = q.d_colors; c->d_ts = q.d_ts; c->d_partial = q.d_partial;
-  c->d_rank = q.d_rank; c->d_size = q.d_size; c->d_order = q.d_order;
+  c->d_rank = q.d_rank; c->d_size = q.d_size; c->d_order = q.d_order; c->d_ll_deferred = q.d_ll_deferred;
 }
 
 // The glibc rand() stream from seed 1, at least `need` values, on the device.
@@ -472,7 +477,7 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   dev_free(&c->d_hits); dev_free(&c->d_nodes); dev_free(&c->d_sorg); dev_free(&c->d_colors); dev_free(&c->d_ts); dev_free(&c->d_partial);
   dev_free(&c->h_rgb_t); dev_free(&c->h_rgb); dev_free(&c->h_mm); dev_free(&c->h_ids_t); dev_free(&c->h_ids); dev_free(&c->h_rgba); dev_free(&c->d_gammas); dev_free(&c->h_map);
   dev_free(&c->d_rank); dev_free(&c->d_size); dev_free(&c->d_order); dev_free(&c->d_ctl); dev_free(&c->d_totals);
-  dev_free(&c->d_ll_offsets); dev_free(&c->d_ll_refs); dev_free(&c->d_ll_faces);
+  dev_free(&c->d_ll_offsets); dev_free(&c->d_ll_refs); dev_free(&c->d_ll_faces); dev_free(&c->d_ll_deferred);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -508,6 +513,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
+  else if (!strcmp(name, "light_list_kernel")) c->opt_ll_kernel = value != 0;
   else if (!strcmp(name, "light_list_levels")) {
     if (value < 1 || value > 4) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_levels: 1..4");
     if (c->opt_ll_levels != (int)value) { c->opt_ll_levels = (int)value; c->ll_tried = false; c->ll.on = 0; }
@@ -1009,7 +1015,16 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
       ll.tri_box = c->d_box;
       const bool lists = c->opt_light_lists && ll.on && c->filter && !c->opt_count && rectest && !ends;
       if (!lists) ll.on = 0;
-      const ShadowArgs sargs{c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], order, ll};
+      ShadowArgs sargs{c->grid, c->shade, c->d_sorg, rr, c->d_ts, (long long)c->total_nodes, c->d_ctl, L, (int)c->base[L], order, ll, nullptr};
+      // The lists' own kernel first, where it applies: one recursion level, point lights only, queue order (a ticket is a
+      // tile's 64 hit points, the queue a whole number of tickets).  What it leaves goes to k_shadow as a list of tickets.
+      const bool lists_kernel = lists && c->opt_ll_kernel && c->levels == 1 && c->npl == 0 && order == nullptr && L == 0 && n0 % 64 == 0 && c->d_ll_deferred;
+      if (lists_kernel) {
+        HIPCHK(c, hipMemsetAsync(c->d_ll_deferred, 0, sizeof(uint32_t), c->stream));
+        const ListsArgs largs{c->grid, c->shade, c->d_sorg, c->d_ts, (long long)c->total_nodes, c->d_ctl, (int)c->base[L], ll, c->d_ll_deferred};
+        KLAUNCH(c, k_shadow_lists, dim3(c->num_cu * RT_WAVES_LISTS), dim3(256), c->stream, largs);
+        sargs.ticket_list = c->d_ll_deferred;
+      }
 #define RT_LAUNCH_SHADOW(COUNT, RECTEST, ENDS) \
   KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, sargs)
 #define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)

@@ -98,3 +98,23 @@ def test_random_opaque_scenes_with_lights_in_hard_places(tmp_path, seed):
     rel = np.abs(on["rgb"][fin] - o["rgb"][fin]) / np.maximum(np.abs(o["rgb"][fin]), 1e-30)
     assert rel.max() <= 1e-4
     print("seed %d: %d tickets from the lists, %d walked" % (seed, con["shadow_list_tickets"], con["shadow_list_fallbacks"]))
+
+
+@pytest.mark.parametrize("w,h", [(960, 540), (777, 431)])
+def test_the_lists_own_kernel_and_the_lists_inside_the_walk_kernel_agree(w, h):
+    """Option "light_list_kernel": the tickets whose hit points cover few texels are settled by a kernel of their own (a
+    tile's hit points for all lights in turn), the others go to the walk kernel as a list of tickets; with 0 the walk
+    kernel looks every ticket up itself.  Same frame, same number of tickets answered from the lists."""
+    os.chdir(ROOT)
+    scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=w, height=h)
+    r = rt.Renderer(0)
+    try:
+        a, ca = frame(r, scene, 1)
+        r.set_option("light_list_kernel", 0)
+        b, cb = frame(r, scene, 1)
+    finally:
+        r.close()
+    assert np.array_equal(a["ids"], b["ids"])
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert ca["shadow_list_tickets"] == cb["shadow_list_tickets"] > 0
+    assert ca["shadow_list_fallbacks"] == cb["shadow_list_fallbacks"]
