@@ -2590,12 +2590,15 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
 // level): what k_shadow<..., LL> does inside its ticket loop, without the walk's code and state around it.  A ticket is 64
 // consecutive shaded hits (a tile's hit points) and goes through all lights in turn: the hit points, their normals,
 // voxels and bounding box are fetched and worked out once for all lights.  Only the narrow cases are settled here (the
-// tile's hit points cover few texels at one of the two finest levels): their cost is even, so the wavefronts finish
+// tile's hit points cover few texels at a level up to RT_LISTS_MAX_LEVEL): their cost is even, so the wavefronts finish
 // together.  A (ticket, light) that is wide, or that the lists cannot settle, is appended to `deferred` (deferred[0]: how
 // many; entries light * (n / 64) + ticket: k_shadow's own ticket numbers) and left to k_shadow, where every such pair is a
 // ticket of its own.
 #ifndef RT_WAVES_LISTS
 #define RT_WAVES_LISTS 6
+#endif
+#ifndef RT_LISTS_MAX_LEVEL
+#define RT_LISTS_MAX_LEVEL 2  // the coarsest level of texels a ticket may need to be settled by k_shadow_lists (temple 4K, both kernels: 0: 2.47 ms, 1: 1.50, 2: 1.42, 3: 1.94)
 #endif
 struct ListsArgs {
   GridP g; ShadeP sp; const SOrigin *sorg; float *ts_out; long long ts_stride; Ctl *ctl; int node_base; LightListsP ll;
@@ -2665,7 +2668,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_LISTS) k_shadow_lists(ListsArgs 
         }
         int hit_id = -1;
         uint32_t diag[3] = {0u, 0u, 0u};
-        if (fan.on && lists_lookup(g, ll, light_i, fan, alive, a, r, pm, onorm, current, dmax, slice, lane, ll.levels > 1 ? 1 : 0, hit_id, diag) &&
+        if (fan.on && lists_lookup(g, ll, light_i, fan, alive, a, r, pm, onorm, current, dmax, slice, lane, ll.levels - 1 < RT_LISTS_MAX_LEVEL ? ll.levels - 1 : RT_LISTS_MAX_LEVEL, hit_id, diag) &&
             lists_verify(ll, alive, hit_id, r, [&](Walk &v, int &vi, int &vj, int &vk) {
               int lo[3], hi[3];
 #pragma unroll
