@@ -164,7 +164,9 @@ def roofline(fam, avg_ms, q, S, T, full_tests, lane_slots, workload):
                             "salu_branch_share": round((pm.get("SQ_INSTS_SALU", 0.0) + pm.get("SQ_INSTS_BRANCH", 0.0)) / insts, 3),
                             "lds_share": round(pm.get("SQ_INSTS_LDS", 0.0) / insts, 3),
                             "cycles_per_instruction_per_simd": round(cycles * simds / insts, 3),
-                            "resident_waves_per_simd": round(pm.get("SQ_WAVES", 0.0) / simds, 2)}
+                            "resident_waves_per_simd": round(pm.get("SQ_WAVES", 0.0) / simds / pm.get("launches_added", 1), 2)}
+            if pm.get("launches_added", 1) > 1:
+                out["issue"]["launches"] = "k_shadow_lists + k_shadow (the light lists' own kernel, then the walk kernel for what it leaves): counters added"
     if tr is not None and secs > 0:
         hbm = tr.get("hbm_bytes_per_launch")
         if hbm:
@@ -185,8 +187,11 @@ def roofline(fam, avg_ms, q, S, T, full_tests, lane_slots, workload):
     out["executed_tests_frac"] = round(lane_slots / T, 4) if T else None
     out["source"] = ("launch time: HIP events of this run; SQ / L2 counters: rocprofv3 --pmc passes under profiles/ on the same "
                      "kernel sources (csrc_sha256), null when stale")
-    out["note"] = ("instruction-issue bound: frac is the share of SIMD cycles that issue a VALU instruction; HBM sees hbm_frac "
-                   "of its peak; logical_gbs counts every listed triangle as if read from memory and is no fraction of a peak")
+    out["note"] = ("frac is the share of SIMD cycles that issue a VALU instruction (the walk kernels run at the machine's issue rate, "
+                   "about 2.1 cycles per instruction and SIMD: issue.cycles_per_instruction_per_simd says how far from it this one "
+                   "is; the shadow queries answered from the light lists wait for memory and for their slowest wavefronts); HBM sees "
+                   "hbm_frac of its peak; logical_gbs counts every listed triangle of the reference's walk as if read from memory "
+                   "and is no fraction of a peak")
     return out
 
 

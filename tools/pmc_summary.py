@@ -43,6 +43,13 @@ for k in acc:
     for fam in ("k_shadow<false", "k_nearest<false"):
         if fam in k:
             out[fam.split("<")[0]] = {c: sum(v) / len(v) for c, v in acc[k].items()}
+for k in acc:
+    # the shadow queries of a frame are two launches where the light lists have a kernel of their own (k_shadow_lists, then
+    # k_shadow for what it leaves): one unit, the counters of the two added (SQ_WAVES is then the waves of both)
+    if "k_shadow_lists" in k and "k_shadow" in out:
+        for c, v in acc[k].items():
+            out["k_shadow"][c] = out["k_shadow"].get(c, 0.0) + sum(v) / len(v)
+        out["k_shadow"]["launches_added"] = 2
 if out:
     json.dump({"method": "rocprofv3 --pmc, means over the launches of one run of tools/kbench.py --one", "workload": workload,
                "csrc_sha256": csrc_hash(), **out}, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1)

@@ -25,6 +25,10 @@ for k in ("k_nearest", "k_shadow", "k_hit", "k_accumulate"):
     if k not in acc:
         continue
     m = {c: sum(v) / len(v) for c, v in acc[k].items()}
+    if k == "k_shadow" and "k_shadow_lists" in acc:
+        # the shadow queries of a frame are two launches there (k_shadow_lists, then k_shadow for what it leaves): one unit
+        for c, v in acc["k_shadow_lists"].items():
+            m[c] = m.get(c, 0.0) + sum(v) / len(v)
     fetch, write = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
     hit, miss = m.get("TCC_HIT_sum", 0.0), m.get("TCC_MISS_sum", 0.0)
     out[k] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
