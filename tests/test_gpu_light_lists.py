@@ -103,12 +103,14 @@ def test_random_opaque_scenes_with_lights_in_hard_places(tmp_path, seed):
 @pytest.mark.parametrize("w,h", [(960, 540), (777, 431)])
 def test_the_lists_own_kernel_and_the_lists_inside_the_walk_kernel_agree(w, h):
     """Option "light_list_kernel": the tickets whose hit points cover few texels are settled by a kernel of their own (a
-    tile's hit points for all lights in turn), the others go to the walk kernel as a list of tickets; with 0 the walk
-    kernel looks every ticket up itself.  Same frame, same number of tickets answered from the lists."""
+    tile's hit points for all lights in turn), the others go to the walk kernel as a list of tickets (2: always; 1, the
+    default: for shares of a frame large enough); with 0 the walk kernel looks every ticket up itself.  Same frame, same
+    number of tickets answered from the lists."""
     os.chdir(ROOT)
     scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=w, height=h)
     r = rt.Renderer(0)
     try:
+        r.set_option("light_list_kernel", 2)
         a, ca = frame(r, scene, 1)
         r.set_option("light_list_kernel", 0)
         b, cb = frame(r, scene, 1)
