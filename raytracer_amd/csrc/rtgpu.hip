@@ -652,11 +652,15 @@ namespace {
 // device.  A scene they do not apply to (a transparent triangle, no point light), or whose lists would be larger than
 // kLLMaxRefs references even with coarser texels, goes without: its shadow queries all take the walk.
 constexpr uint64_t kLLMaxRefs = 128ull << 20;
-int ensure_light_lists(rtgpu_ctx *c) {
+constexpr uint64_t kLLMaxPairs = 1ull << 20;
+int build_light_lists(rtgpu_ctx *c) {
   if (c->ll_tried) return RTGPU_OK;
   c->ll_tried = true;
   c->ll.on = 0;
   if (!c->all_opaque || c->nl <= 0 || c->nt <= 0) return RTGPU_OK;
+  // (the rectangles are worked out on the host, about a microsecond per triangle and light: a scene of very many of both
+  // keeps its walks rather than wait seconds for its first frame)
+  if ((uint64_t)c->nt * (uint64_t)c->nl > kLLMaxPairs) return RTGPU_OK;
   std::vector<float> lp(3 * (size_t)c->nl);
   for (int k = 0; k < c->nl; k++) for (int q = 0; q < 3; q++) lp[3 * (size_t)k + q] = c->lights[k].p[q];
   LightListsHost h;
@@ -731,6 +735,19 @@ int ensure_light_lists(rtgpu_ctx *c) {
   c->ll.olim = h.olim; c->ll.R = R; c->ll.on = 1; c->ll.levels = levels;
   c->ll.texels0 = (uint32_t)ntex0;
   return RTGPU_OK;
+}
+// The lists are an accelerator, not a need: if they cannot be built (no memory for them), the scene keeps its walks.
+int ensure_light_lists(rtgpu_ctx *c) {
+  if (c->ll_tried) return RTGPU_OK;
+  const int rc = build_light_lists(c);
+  if (rc == RTGPU_E_MEMORY) {
+    (void)hipGetLastError();
+    dev_free(&c->d_ll_offsets); dev_free(&c->d_ll_refs); dev_free(&c->d_ll_faces);
+    c->cap_ll_texels = c->cap_ll_refs = c->cap_ll_faces = 0;
+    c->ll.on = 0;
+    return RTGPU_OK;
+  }
+  return rc;
 }
 }  // namespace
 
