@@ -117,6 +117,9 @@ typedef struct rtgpu_counters {
   /* Shadow tickets (64 shadow queries of one light) answered from the light's lists, and tickets the lists were tried
    * for but which took the walk after all (option "light_lists"; counted without "count" too). */
   int64_t shadow_list_tickets, shadow_list_fallbacks;
+  /* Tickets of primary rays (the 64 pixels of a tile) answered from the frame's view lists, and tickets the lists were
+   * tried for but which took the walk after all (option "view_lists"; counted without "count" too). */
+  int64_t view_list_tickets, view_list_fallbacks;
 } rtgpu_counters;
 
 /* Per-kernel device time since the previous rtgpu_timings_get, summed per kernel family, from HIP
@@ -296,6 +299,15 @@ int rtgpu_math_selfcheck(rtgpu_ctx *ctx, uint64_t mismatches[2]);
 int rtgpu_light_list_pairs(int64_t n, const float *verts, const float *lights, float olim, double *out);
 int rtgpu_light_list_rects(int32_t nt, const float *verts, int32_t nl, const float *lights, int32_t R, float olim, int64_t cap,
                            uint32_t *rects, float *faces, float *olim_out, int64_t *n_rects, int64_t *refs);
+
+/* Diagnostics of the view lists, no counterpart in the reference, host code only (no GPU needed).  The nearest-hit
+ * queries of the primary rays (src/raytrace.c:306-340, src/voxelize.c:536-613) are answered from a table over the screen
+ * (option "view_lists", built with every frame's set-up): the screen cut into texels of 8 x 8 pixels or a power of two
+ * times that, each listing the triangles the reference's test (src/intersection.c:58-86) can accept for the ray of one of
+ * its pixels.  This call returns what the table is filled from: for n triangles (verts n x 9: i, j, k) and one camera for
+ * all of them (ncams = 1) or one each (ncams = n), out[n][5] = found (0 / 1) and the rectangle of pixels, columns a0..a1 and
+ * rows b0..b1, outside which no pixel's ray can be accepted for the triangle. */
+int rtgpu_view_list_rects(int64_t n, const float *verts, const rtgpu_camera *cams, int64_t ncams, int32_t *out);
 
 /* Single-GPU convenience for a C host: frame_begin must have been called; renders all tiles and
  * returns row-major host arrays (rgb w*h*3, ids w*h, minmax 6).  Any output may be NULL. */

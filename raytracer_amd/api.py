@@ -60,7 +60,8 @@ class Counters(C.Structure):
                                          "shadow_stage2", "shadow_stage3", "shadow_exact", "nearest_visits", "shadow_visits", "nearest_batches",
                                          "nearest_batches_culled", "shadow_batches", "shadow_batches_culled",
                                          "nearest_full_tests", "shadow_full_tests", "chunks", "chunks_rerendered",
-                                         "shadow_list_tickets", "shadow_list_fallbacks")]
+                                         "shadow_list_tickets", "shadow_list_fallbacks",
+                                         "view_list_tickets", "view_list_fallbacks")]
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -9,6 +9,7 @@
 #pragma once
 #include "rt_math.h"
 #include "rt_texture.h"
+#include "rt_viewlists.h"
 
 #ifndef RT_DENSE
 #define RT_DENSE 7  // a batch with at least this many records left by the bundle's test has all its records tested in fixed groups of four
@@ -1497,13 +1498,132 @@ RT_D T fresh_arg(size_t offset) {
   return T();  // (the host pass only parses the kernels)
 #endif
 }
+// ------------------------------------------------------------------------------------------------
+// Primary rays from the view lists (rt_viewlists.h; ViewListsP), for the 64 pixels of a tile.  The texel's list holds
+// every triangle the exact test can accept for any of the tile's rays.  64 references per pass: one lane per triangle
+// gathers its record and culls it for the whole tile (apex_slabs_pass), what is left goes through LDS to the test every
+// lane runs (test(record): the walk's own, with no voxel's exit distance in force).
+//
+// Can ANY ray of a bundle that starts at ONE point o pass the three slabs of this record, with a hit in front of o?
+// false only if surely none can.  With a common origin the filter's quantities are linear in the direction:
+// det = r.N, tp = r.W1, nv = r.W2 with W1 = ik x o - Q, W2 = ij x o + P (rt_math.h: tp = m.ik - r.Q, nv = m.ij + r.P, m = o x r), so
+// X1 = r.(2 W1 - N), X2 = r.(-2 W2 - N), X3 = r.(2 W1 - 2 W2 - N) and over |r - axis| <= rho each stays within rho |gradient| of
+// its value at the axis.  tri_test accepts a ray only if |X*| <= |det*| (1 + 7 eps) + kc for each (bundle_slabs_pass); the
+// values worked out here are within kc / 4 of the exact ones (W1, W2 in binary32: 4 eps L (|o| + A) each), so no ray passes if
+//     |X(axis)| - 1.001 rho |gradient| > 1.00001 (|det(axis)| + rho |N|) + 2 kc_max.
+// In front: d = dp / det with dp = i.N - o.N the same for all rays; as in fan_plane_behind no ray is accepted if
+// |det(axis)| - rho |N| > 1.5 kc_max (one sign, large enough) and sign(det) dp < -2 |ik| kc_max.  A NaN compares false: passes.
+RT_D bool apex_slabs_pass(const RecA &A, f3 ab, f3 P, float an, float kc_max, f3 o, f3 axis, float rho) {
+  const f3 w1 = mk3(__builtin_fmaf(A.ac.y, o.z, __builtin_fmaf(-A.ac.z, o.y, -A.q.x)), __builtin_fmaf(A.ac.z, o.x, __builtin_fmaf(-A.ac.x, o.z, -A.q.y)),
+                    __builtin_fmaf(A.ac.x, o.y, __builtin_fmaf(-A.ac.y, o.x, -A.q.z)));
+  const f3 w2 = mk3(__builtin_fmaf(ab.y, o.z, __builtin_fmaf(-ab.z, o.y, P.x)), __builtin_fmaf(ab.z, o.x, __builtin_fmaf(-ab.x, o.z, P.y)),
+                    __builtin_fmaf(ab.x, o.y, __builtin_fmaf(-ab.y, o.x, P.z)));
+  const f3 g1 = mk3(__builtin_fmaf(2.0f, w1.x, -A.n.x), __builtin_fmaf(2.0f, w1.y, -A.n.y), __builtin_fmaf(2.0f, w1.z, -A.n.z));
+  const f3 g2 = mk3(__builtin_fmaf(-2.0f, w2.x, -A.n.x), __builtin_fmaf(-2.0f, w2.y, -A.n.y), __builtin_fmaf(-2.0f, w2.z, -A.n.z));
+  const f3 g3 = mk3(__builtin_fmaf(-2.0f, w2.x, g1.x), __builtin_fmaf(-2.0f, w2.y, g1.y), __builtin_fmaf(-2.0f, w2.z, g1.z));
+  auto along = [&](f3 v) { return __builtin_fmaf(axis.x, v.x, __builtin_fmaf(axis.y, v.y, axis.z * v.z)); };
+  auto norm = [&](f3 v) { return __builtin_amdgcn_sqrtf(__builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z))) * 1.001f; };
+  const float det = along(A.n), rn = rho * norm(A.n);
+  const float T = __builtin_fmaf(__builtin_fabsf(det) + rn, 1.00001f, kc_max + kc_max);
+  const bool out = (__builtin_fabsf(along(g1)) - rho * norm(g1) > T) | (__builtin_fabsf(along(g2)) - rho * norm(g2) > T) |
+                   (__builtin_fabsf(along(g3)) - rho * norm(g3) > T);
+  const float dp = __builtin_fmaf(-o.x, A.n.x, __builtin_fmaf(-o.y, A.n.y, __builtin_fmaf(-o.z, A.n.z, an)));
+  const float sdp = __int_as_float(__float_as_int(dp) ^ (__float_as_int(det) & (int)0x80000000));
+  const bool behind = (__builtin_fabsf(det) - rn > 1.5f * kc_max) & (sdp < -2.0f * norm(A.ac) * kc_max);
+  return !(out | behind);
+}
+// in: the lanes whose rays take part (all with the origin o); beg .. end: the texel's references
+template <typename T>
+RT_D void view_candidates(const GridP &g, const int32_t *__restrict__ refs, uint32_t beg, uint32_t end, bool in, f3 o, f3 r, float onorm,
+                          float *slice, int lane, uint32_t (&diag)[3], T &&test) {
+  const int mid = central_lane(in, lane, true, 0);
+  const f3 axis = lane_bcast3(r, mid), o_all = lane_bcast3(o, mid);
+  const f3 dr = sub3(r, axis);
+  float rho_own = in ? __builtin_fmaf(__builtin_amdgcn_sqrtf(dot3(dr, dr)), 1.001f, 1e-7f) : 0.0f;
+  if (!(rho_own >= 0.0f)) rho_own = INFINITY;  // (a NaN would be dropped by the maximum)
+  const float rho = lane_bcast(wave_max(rho_own), 0);
+  float on_own = in ? onorm : 0.0f;
+  if (!(on_own >= 0.0f)) on_own = INFINITY;
+  const float onorm_all = lane_bcast(wave_max(on_own), 0);
+  constexpr int kSlots = kSliceFloats / kRecFloats;  // records of the slice for a pass's survivors
+  static_assert(kSlots >= 32, "most passes fit the slice at once");
+  for (uint32_t e0 = beg; e0 < end; e0 += 64u) {
+    bool pass = false;
+    const v4f *R = nullptr;
+    if (e0 + (uint32_t)lane < end) {
+      R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)refs[e0 + lane]);
+      const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+      RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
+      const float kc_max = __builtin_fmaf(r0.w, onorm_all, r2.w) + g.slack;
+      pass = apex_slabs_pass(A, mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), r4.z, kc_max, o_all, axis, rho);
+    }
+    diag[1] += (uint32_t)__popcll(__ballot(e0 + (uint32_t)lane < end));
+    unsigned long long todo = __ballot(pass);
+    while (todo != 0) {
+      const int before = __popcll(todo & lanes_below(lane));
+      const bool mine = ((todo >> lane) & 1ull) != 0 && before < kSlots;
+      if (mine) {
+        v4f *D = reinterpret_cast<v4f *>(slice + before * kRecFloats);
+        const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+        D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4;
+      }
+      const unsigned long long placed = __ballot(mine);
+      todo &= ~placed;
+      __builtin_amdgcn_wave_barrier();
+      const int n = __popcll(placed);
+      diag[2] += (uint32_t)n;
+      for (int q2 = 0; q2 < n; q2++) test(slice + q2 * kRecFloats);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+// The nearest candidates against the walks.  The reference's walk (voxelize.c:536-613) takes, in the first cell of the walk
+// that has one, the nearest accepted triangle that the cell lists and that lies before the cell's exit distance.  With
+// best the smallest distance among ALL accepted triangles of the scene (ties: the smallest index) no cell whose exit
+// distance is at most best can have such a triangle; so if the first cell with a larger exit distance lists that
+// triangle, the walk stops there with it.  Steps every lane that has a candidate (need) to that cell with the reference's
+// accumulated-sum DDA and looks the cell up in the triangle's voxel box (= the cells that list it); the walk comes out
+// standing in that cell.  false: some lane's candidate is not confirmed that way (nothing is decided then).
+RT_D bool view_verify(const GridP &g, const int32_t *__restrict__ tri_box, bool need, int best_id, float best, f3 r, int vi, int vj, int vk, Walk &v) {
+  bool failed = false;
+  if (__ballot(need) != 0) {
+    int lo0 = 0, lo1 = 0, lo2 = 0, hi0 = -1, hi1 = -1, hi2 = -1;
+    if (need) {
+      const int32_t *bx = tri_box + 6 * (size_t)best_id;
+      lo0 = bx[0]; lo1 = bx[1]; lo2 = bx[2]; hi0 = bx[3]; hi1 = bx[4]; hi2 = bx[5];
+      if ((v.nx | v.ny | v.nz) < 0) { need = false; failed = true; }
+    }
+    const int si = r.x > 0.0f ? 1 : -1, sj = r.y > 0.0f ? 1 : -1, sk = r.z > 0.0f ? 1 : -1;
+    for (;;) {
+      const float xn = v.tx + v.dtx, yn = v.ty + v.dty, zn = v.tz + v.dtz;
+      if (need && best < min3_ref(xn, yn, zn)) {
+        need = false;
+        failed = !(vi >= lo0 && vi <= hi0 && vj >= lo1 && vj <= hi1 && vk >= lo2 && vk <= hi2);
+      }
+      if (__ballot(need) == 0) break;
+      if (need) {  // walk_step, with the voxel's indices instead of the cell's
+        const bool xy = xn < yn;
+        const bool sx = xy & (xn < zn), sy = !xy & (yn < zn);
+        v.tx = sx ? xn : v.tx; v.ty = sy ? yn : v.ty; v.tz = (sx | sy) ? v.tz : zn;
+        v.nx -= sx ? 1 : 0; v.ny -= sy ? 1 : 0; v.nz -= (sx | sy) ? 0 : 1;
+        vi += sx ? si : 0; vj += sy ? sj : 0; vk += (sx | sy) ? 0 : sk;
+        if ((v.nx | v.ny | v.nz) < 0) { need = false; failed = true; }
+      }
+    }
+    v.cell = cell_index(g, vi, vj, vk);
+  }
+  return __ballot(failed) == 0;
+}
 // k_nearest's arguments: one structure, so that a member's offset in it is its offset in the argument segment
 struct NearestArgs {
   GridP g; const Ray *rays; Hit *hits; Ctl *ctl; int level; PrimaryP prim;
   ShadeP sp; Node *nodes; SOrigin *sorg; int node_base;  // for the instances that shade their hits themselves (FUSE)
+  ViewListsP vl;  // for the instance that takes the primary rays' hits from the view lists (VL)
 };
-template <bool COUNT, bool RECTEST, bool FUSE>
+// VL: the tickets of primary rays are answered from the view lists where they can be (view_candidates, view_verify)
+template <bool COUNT, bool RECTEST, bool FUSE, bool VL = false>
 __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs args) {
+  static_assert(!VL || !COUNT, "the counting variant reports the reference's walks");
   const GridP &g = args.g;
   const Ray *__restrict__ rays = args.rays;
   Hit *__restrict__ hits = args.hits;
@@ -1520,9 +1640,35 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
   const TriRec *__restrict__ recs = g.cell_tris;
   unsigned long long nS = 0, nT = 0, nLane = 0, nWave = 0, nQ = 0, nS2 = 0, nS3 = 0, nEx = 0, nVisit = 0, nBatch = 0, nCull = 0, nFull = 0;
   uint32_t nPixels = 0, nTraced = 0, nHits = 0;  // wave-uniform tallies, one atomic each per wavefront
+  uint32_t nViewed = 0, nViewFell = 0;           // tickets answered from the view lists / tried there and walked after all
   Phases ph;
   ph.begin();
   RT_TICKET(const unsigned long long born = __builtin_amdgcn_s_memtime(); unsigned long long busy = 0;)
+  // One triangle for one ray: the filter, then tri_test for what it cannot decide.  Everything after the
+  // first slab sits behind one scalar branch that is taken only if some lane of the wavefront passed it.
+  auto test = [&](const float *R, f3 to, f3 tr, f3 tm, float kc, int cur, float &b, int &bid, float &bu, float &bv,
+                  uint32_t pos, uint32_t &bpos) {
+    const RecA A = rec_a(R);
+    PlTest t;
+    const bool p1 = pl_stage1(A.n, A.ac, A.q, tr, tm, kc, t);
+    if (wave_any(p1)) {
+      asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into the per-lane one
+      bool s3 = false, ex = false;
+      if (p1) ex = nearest_needs_exact(R, A, t, to, tr, tm, kc, g.lmax, b, s3);
+      if (COUNT) { nS2++; nS3 += __ballot(s3) != 0; nEx += __ballot(ex) != 0; }
+      if (ex) {
+        const int id = rec_id(R);
+        float d, u, v;
+        // the reference keeps the first of equal distances in its ascending list = the smallest triangle index; written
+        // on the index, the choice does not depend on the order the list is walked in (bid = -1: the voxel's exit distance)
+        bool full = false;
+        if (exact_test(g, id, to, tr, d, u, v, COUNT ? &full : nullptr) && id != cur && (d < b || (d == b && id < bid))) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
+        if (COUNT && full) nFull++;
+      }
+      return true;
+    }
+    return false;
+  };
   Tickets tickets((unsigned long long)nrays);
   for (;;) {
     uint32_t base;
@@ -1558,11 +1704,50 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
       walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, !COUNT, w);  // (the counting variant reports the reference's step counts)
       // stand on the first non-empty cell of the walk (the start voxel counts as visited)
       if (COUNT) nS++;
-      if (!cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
-      if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
-        mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
-        if (COUNT) nT += mycnt;
+      if (!VL) {
+        if (!cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
+        if (alive) {  // the list of the cell the walk stands on, fetched once the lanes are together again
+          mybeg = cstart[w.cell]; mycnt = cstart[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell];
+          if (COUNT) nT += mycnt;
+        }
       }
+    }
+    if (VL) {
+      ph.end<0>();
+      // The view lists instead of the walk, for a ticket of primary rays.  Where they do not apply (the frame's lists did
+      // not fit their buffer) or do not agree with a ray's walk, the ticket takes the walk below, from its untouched state.
+      const GridP g = fresh_arg<GridP>(offsetof(NearestArgs, g));
+      const ViewListsP vl = fresh_arg<ViewListsP>(offsetof(NearestArgs, vl));
+      const PrimaryP prim = fresh_arg<PrimaryP>(offsetof(NearestArgs, prim));
+      if (vl.on && prim.on && __ballot(alive) != 0) {
+        const long long gt = (long long)(prim.tile0 + (int)(base >> 6)) * prim.world + prim.rank;
+        const int tcol = (int)(gt % prim.tiles_x) >> vl.shift, trow = (int)(gt / prim.tiles_x) >> vl.shift;
+        const uint32_t texel = (uint32_t)(trow * vl.ntx + tcol);
+        const uint32_t lbeg = vl.offsets[texel], lend = vl.offsets[texel + 1], lall = vl.offsets[vl.ntx * vl.nty];
+        if (lall <= vl.cap && tcol < vl.ntx && trow < vl.nty) {
+          nViewFell++;
+          float best = INFINITY, best_u = 0.0f, best_v = 0.0f;
+          int best_id = -1;
+          uint32_t nopos = 0;
+          uint32_t diag[3] = {0u, 0u, 0u};
+          view_candidates(g, vl.refs, lbeg, lend, alive, o, r, onorm, slice, lane, diag, [&](const float *R) {
+            const float kc = alive ? __builtin_fmaf(R[3], onorm, R[11]) + g.slack : -INFINITY;
+            test(R, o, r, pm, kc, ry.current, best, best_id, best_u, best_v, 0u, nopos);
+          });
+          Walk v = w;
+          if (view_verify(g, vl.tri_box, alive && best_id >= 0, best_id, best, r, ry.i, ry.j, ry.k, v)) {
+            if (alive && best_id >= 0) { h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v; w = v; }
+            alive = false;
+            nViewed++; nViewFell--;
+          }
+          RT_TICKET(tl.visits = diag[0]; tl.batches = diag[1]; tl.tests = diag[2];)  // (diagnostic build: what the ticket looked at)
+        }
+      }
+      if (__ballot(alive) != 0) {  // the ticket walks after all: what the set-up left out
+        if (alive && !cell_occupied(g, occ_s, occ_in_lds, w.cell)) alive = walk_to_occupied<COUNT>(g, occ_s, occ_in_lds, r, w, nS);
+        if (alive) { mybeg = g.cell_start[w.cell]; mycnt = g.cell_start[w.cell + 1] - mybeg; myhbeg = g.hdr_start[w.cell]; }
+      }
+      ph.end<7>();
     }
     ph.end<0>();
     for (;;) {
@@ -1585,31 +1770,6 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
       int best_id = -1;
       float best_u = 0.0f, best_v = 0.0f;
       bool proc;  // this lane's current cell is fully tested after this step
-      // One triangle for one ray: the filter, then tri_test for what it cannot decide.  Everything after the
-      // first slab sits behind one scalar branch that is taken only if some lane of the wavefront passed it.
-      auto test = [&](const float *R, f3 to, f3 tr, f3 tm, float kc, int cur, float &b, int &bid, float &bu, float &bv,
-                      uint32_t pos, uint32_t &bpos) {
-        const RecA A = rec_a(R);
-        PlTest t;
-        const bool p1 = pl_stage1(A.n, A.ac, A.q, tr, tm, kc, t);
-        if (wave_any(p1)) {
-          asm volatile("; some lane passed the first slab");  // keeps the scalar branch from being merged into the per-lane one
-          bool s3 = false, ex = false;
-          if (p1) ex = nearest_needs_exact(R, A, t, to, tr, tm, kc, g.lmax, b, s3);
-          if (COUNT) { nS2++; nS3 += __ballot(s3) != 0; nEx += __ballot(ex) != 0; }
-          if (ex) {
-            const int id = rec_id(R);
-            float d, u, v;
-            // the reference keeps the first of equal distances in its ascending list = the smallest triangle index; written
-            // on the index, the choice does not depend on the order the list is walked in (bid = -1: the voxel's exit distance)
-            bool full = false;
-            if (exact_test(g, id, to, tr, d, u, v, COUNT ? &full : nullptr) && id != cur && (d < b || (d == b && id < bid))) { b = d; bid = id; bu = u; bv = v; bpos = pos; }
-            if (COUNT && full) nFull++;
-          }
-          return true;
-        }
-        return false;
-      };
       uint32_t nopos = 0;
       if (mode == kCellMode) {
         proc = in_group;
@@ -1733,6 +1893,10 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
       atomicAdd(&ctl->stat[kPixelsTraced], (unsigned long long)nTraced);
     }
     atomicAdd(&ctl->stat[kShaded], (unsigned long long)nHits);
+    if (VL && (nViewed | nViewFell) != 0u) {
+      atomicAdd(&ctl->stat[kViewListTickets], (unsigned long long)nViewed);
+      atomicAdd(&ctl->stat[kViewListFallbacks], (unsigned long long)nViewFell);
+    }
   }
   if (COUNT) {
     // wave-level sums, one atomic per counter per wavefront
@@ -1864,6 +2028,62 @@ __global__ void __launch_bounds__(256) k_ll_fill(const LLRectD *__restrict__ rec
   const uint32_t base = level_base + (faces[r.face].base >> (2 * level));
   LLRef ref; ref.tri = r.tri; ref.rect = (uint32_t)a0 | (uint32_t)a1 << 8 | (uint32_t)b0 << 16 | (uint32_t)b1 << 24;  // the rectangle in this level's texels
   for (int e = lane; e < total; e += 64) refs[atomicAdd(&cursor[base + (uint32_t)((b0 + e / nw) * Rl + a0 + e % nw)], 1u)] = ref;
+}
+// View lists (rt_viewlists.h, ViewListsP), built for every frame.  k_view_rects: every triangle's rectangle of texels and
+// the number of 64-texel pieces it is cut into (scanned by k_order_scan + k_order_scan_totals + k_ll_starts, like the
+// texels' counts afterwards).  k_view_pieces writes down which triangle every piece belongs to; k_view_scatter: one
+// wavefront per piece, whatever triangles they belong to (a floor across the whole screen is thousands of texels, most
+// triangles are one or two).
+// FILL = false: references per texel; FILL = true: the references, unless the frame needs more of them than there is room
+// for (k_nearest sees the same number and leaves the lists alone).
+__global__ void __launch_bounds__(256) k_view_rects(int nt, const float *__restrict__ verts, CameraD cam, int shift, ViewRectD *__restrict__ rects,
+                                                    uint32_t *__restrict__ pieces) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > nt) return;
+  if (t == nt) { pieces[nt] = 0u; return; }
+  ViewRect r;
+  ViewRectD o; o.ab = 1u; o.cd = 0u;
+  uint32_t n = 0u;
+  if (view_rect(verts + 9 * (size_t)t, cam, r)) {
+    const int s = 3 + shift;
+    const uint32_t a0 = (uint32_t)(r.a0 >> s), a1 = (uint32_t)(r.a1 >> s), b0 = (uint32_t)(r.b0 >> s), b1 = (uint32_t)(r.b1 >> s);
+    o.ab = a0 | a1 << 16; o.cd = b0 | b1 << 16;
+    n = ((a1 - a0 + 1u) * (b1 - b0 + 1u) + 63u) / 64u;
+  }
+  rects[t] = o;
+  pieces[t] = n;
+}
+// piece_tri[p] = the triangle piece p belongs to (one thread per triangle writes its pieces' entries)
+__global__ void __launch_bounds__(256) k_view_pieces(int nt, const uint32_t *__restrict__ piece_start, uint32_t cap_pieces, int32_t *__restrict__ piece_tri) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const uint32_t p0 = piece_start[t], p1 = piece_start[t + 1] < cap_pieces ? piece_start[t + 1] : cap_pieces;
+  for (uint32_t p = p0; p < p1; p++) piece_tri[p] = t;
+}
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_view_scatter(const ViewRectD *__restrict__ rects, const uint32_t *__restrict__ piece_start, const int32_t *__restrict__ piece_tri,
+                                                      uint32_t cap_pieces, int nt, int ntx, int ntexels, uint32_t cap, uint32_t *__restrict__ counts_or_cursor,
+                                                      const uint32_t *__restrict__ offsets, int32_t *__restrict__ refs) {
+  const uint32_t total = piece_start[nt];
+  if (total > cap_pieces) {  // (more pieces than piece_tri holds: then more references than their buffer holds, too; the count says so)
+    if (!FILL && blockIdx.x == 0 && threadIdx.x == 0) counts_or_cursor[0] = cap + 1u;
+    return;
+  }
+  if (FILL && offsets[ntexels] > cap) return;
+  const int lane = lane_id();
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t W = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); W < total; W += nwaves) {
+    const int t = piece_tri[W];
+    const ViewRectD r = rects[t];
+    const uint32_t a0 = r.ab & 0xffffu, a1 = r.ab >> 16, b0 = r.cd & 0xffffu, b1 = r.cd >> 16;
+    const uint32_t nw = a1 - a0 + 1u, cells = nw * (b1 - b0 + 1u);
+    const uint32_t e = (W - piece_start[t]) * 64u + (uint32_t)lane;
+    if (e < cells) {
+      const uint32_t texel = (b0 + e / nw) * (uint32_t)ntx + a0 + e % nw;
+      if (FILL) refs[atomicAdd(&counts_or_cursor[texel], 1u)] = t;
+      else atomicAdd(&counts_or_cursor[texel], 1u);
+    }
+  }
 }
 __global__ void __launch_bounds__(256) k_order_place(GridP g, const SOrigin *__restrict__ sorg, const Ctl *__restrict__ ctl, int level,
                                                      int node_base, int parts, uint32_t *__restrict__ bucket, const uint32_t *__restrict__ totals,

@@ -166,6 +166,19 @@ __host__ __device__ inline uint32_t ll_level_base(uint32_t texels0, int level) {
   return level == 0 ? 0u : level == 1 ? texels0 : level == 2 ? texels0 + (texels0 >> 2) : texels0 + (texels0 >> 2) + (texels0 >> 4);
 }
 
+// View lists (rt_viewlists.h): the screen cut into ntx x nty texels of (8 << shift)^2 pixels, a texel listing the triangles
+// the primary ray of one of its pixels can hit.  refs[offsets[t] .. offsets[t + 1]) is texel t's list, t = row * ntx + column;
+// offsets[ntx * nty] is the number of references the frame's lists need: beyond cap they were not written and are not used.
+struct ViewRectD { uint32_t ab, cd; };  // a triangle's texels: columns a0 | a1 << 16, rows b0 | b1 << 16; a0 > a1: none
+struct ViewListsP {
+  const uint32_t *offsets;
+  const int32_t *refs;
+  const int32_t *tri_box;  // per triangle the voxel index box lo[3], hi[3] of this frame's grid
+  uint32_t cap;
+  int32_t ntx, nty, shift, on;
+  int32_t pad;
+};
+
 // Device-side control block of one chunk: queue lengths and statistics (the allocation continues with the ticket counters
 // of the persistent kernels, kCtlBytes in all).
 struct Ctl {
@@ -178,7 +191,8 @@ struct QueueCaps { int32_t cap[kMaxLevels + 1]; };
 enum Stat { kPixels = 0, kPixelsTraced, kNearestQ, kShadowQ, kShadowWalks, kNearS, kNearT, kShadS, kShadT,
             kNearLaneTests, kNearWaveTests, kShaded, kShadLaneTests, kShadWaveTests,
             kNearStage2, kNearStage3, kNearExact, kShadStage2, kShadStage3, kShadExact,
-            kNearVisits, kShadVisits, kNearBatches, kNearCulled, kShadBatches, kShadCulled, kNearFull, kShadFull, kShadListTickets, kShadListFallbacks, kStatCount };
+            kNearVisits, kShadVisits, kNearBatches, kNearCulled, kShadBatches, kShadCulled, kNearFull, kShadFull, kShadListTickets, kShadListFallbacks,
+            kViewListTickets, kViewListFallbacks, kStatCount };
 constexpr int kTotals = 40;  // frame totals: kStatCount counters, then the queue length of every level
 static_assert(kStatCount <= 32 && kStatCount + kMaxLevels <= kTotals, "the statistics fit the control block and the totals buffer");
 

@@ -90,6 +90,8 @@ struct rtgpu_ctx {
     BatchHdr *d_hdrs = nullptr;
       TriRec *d_recs = nullptr;
     int32_t *d_refs = nullptr;
+    uint32_t *d_vl_offsets = nullptr;
+    int32_t *d_vl_refs = nullptr;
   } alt;
   hipStream_t build_stream = nullptr;
   hipEvent_t ev_built = nullptr, ev_released[2] = {nullptr, nullptr};
@@ -160,6 +162,15 @@ struct rtgpu_ctx {
   LLFaceD *d_ll_faces = nullptr;
   size_t cap_ll_texels = 0, cap_ll_refs = 0, cap_ll_faces = 0;
   uint32_t *d_ll_deferred = nullptr;  // (ticket, light) pairs k_shadow_lists leaves to k_shadow (one of the chunk's queues)
+  // view lists (rt_viewlists.h): built with every frame's set-up; offsets and references belong to the frame's set (alt: the other set's)
+  bool opt_view_lists = true;  // option "view_lists"
+  int opt_vl_shift = 1;        // option "view_list_texel_shift": a texel is at least 2^shift tiles a side (temple 3840x2160: 2.11, 2.04, 2.03 ms a frame with 0, 1, 2)
+  ViewListsP vl = {};
+  uint32_t *d_vl_offsets = nullptr, *d_vl_pieces = nullptr, *d_vl_cursor = nullptr, *d_vl_totals = nullptr;
+  int32_t *d_vl_refs = nullptr, *d_vl_piece_tri = nullptr;
+  ViewRectD *d_vl_rects = nullptr;
+  size_t cap_vl_texels = 0, cap_vl_refs = 0, cap_vl_nt = 0;
+  bool vl_no_memory = false;  // an allocation for them failed once: this context goes without
   int opt_ll_kernel = 1;  // option "light_list_kernel": the lists' own kernel where it applies: 0 never (inside k_shadow only), 1 where a wavefront gets many tickets, 2 always
   // timing
   std::vector<TimedSpan> spans;
@@ -208,6 +219,7 @@ void swap_grid_sets(rtgpu_ctx *c) {
   std::swap(c->d_cell_start, c->alt.d_cell_start); std::swap(c->d_hdr_start, c->alt.d_hdr_start); std::swap(c->d_occ, c->alt.d_occ);
   std::swap(c->d_hdrs, c->alt.d_hdrs); std::swap(c->d_recs, c->alt.d_recs);
   std::swap(c->d_refs, c->alt.d_refs);
+  std::swap(c->d_vl_offsets, c->alt.d_vl_offsets); std::swap(c->d_vl_refs, c->alt.d_vl_refs);
   c->parity ^= 1;
 }
 // The kernels that read the current set are enqueued up to here.
@@ -466,6 +478,8 @@ void rtgpu_destroy(rtgpu_ctx *c) {
   resolve_spans(c);
   dev_free(&c->alt.d_geom); dev_free(&c->alt.d_aux); dev_free(&c->alt.d_cell_start); dev_free(&c->alt.d_hdr_start); dev_free(&c->alt.d_occ);
   dev_free(&c->alt.d_hdrs); dev_free(&c->alt.d_recs); dev_free(&c->alt.d_refs);
+  dev_free(&c->alt.d_vl_offsets); dev_free(&c->alt.d_vl_refs); dev_free(&c->d_vl_offsets); dev_free(&c->d_vl_refs);
+  dev_free(&c->d_vl_pieces); dev_free(&c->d_vl_cursor); dev_free(&c->d_vl_totals); dev_free(&c->d_vl_rects); dev_free(&c->d_vl_piece_tri);
   if (c->ev_built) (void)hipEventDestroy(c->ev_built);
   for (int k = 0; k < 2; k++) if (c->ev_released[k]) (void)hipEventDestroy(c->ev_released[k]);
   if (c->build_stream) (void)hipStreamDestroy(c->build_stream);
@@ -513,6 +527,8 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
+  else if (!strcmp(name, "view_lists")) c->opt_view_lists = value != 0;
+  else if (!strcmp(name, "view_list_texel_shift")) { if (value < 0 || value > 4) return fail(c, RTGPU_E_INVALID_PARAM, "view_list_texel_shift: 0..4"); c->opt_vl_shift = (int)value; }
   else if (!strcmp(name, "light_list_kernel")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_kernel: 0, 1 or 2"); c->opt_ll_kernel = (int)value; }
   else if (!strcmp(name, "light_list_levels")) {
     if (value < 1 || value > 4) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_levels: 1..4");
@@ -749,6 +765,83 @@ int ensure_light_lists(rtgpu_ctx *c) {
   }
   return rc;
 }
+// The view lists of the frame being set up (rt_viewlists.h), on the stream bs, into the set of buffers swap_grid_sets has
+// just made current.  The screen's texels: one per tile of 8 x 8 pixels, or 2^shift tiles a side where that would be more
+// than 2^18 texels.  The references get a buffer planned from the scene and the screen (64 per texel and 16 per triangle,
+// a million at least); a frame that needs more goes without (the kernels see the number the frame needs next to the
+// buffer's size).  Buffers that cannot be had: this context keeps its walks.
+int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
+  c->vl.on = 0;
+  if (!c->opt_view_lists || c->vl_no_memory || c->nt <= 0) return RTGPU_OK;
+  const int tiles_x = (c->cam.sw + kTile - 1) / kTile, tiles_y = (c->cam.sh + kTile - 1) / kTile;
+  int shift = c->opt_vl_shift;
+  while ((int64_t)((tiles_x >> shift) + 1) * ((tiles_y >> shift) + 1) > (1 << 18) && shift < 12) shift++;
+  const int ntx = ((tiles_x - 1) >> shift) + 1, nty = ((tiles_y - 1) >> shift) + 1;
+  if (ntx > 65535 || nty > 65535 || (int64_t)ntx * nty > (1 << 18)) return RTGPU_OK;
+  const size_t ntexels = (size_t)ntx * nty;
+  const size_t want_refs = std::max<size_t>((size_t)1 << 20, 64 * ntexels + 16 * (size_t)c->nt);
+  const int nscan_t = (int)((ntexels + 1 + kScanTile - 1) / kScanTile), nscan_p = (int)(((size_t)c->nt + 1 + kScanTile - 1) / kScanTile);
+  auto grow = [&]() -> int {
+    int rc;
+    if (ntexels + 2 > c->cap_vl_texels) {
+      c->cap_vl_texels = 0;
+      if ((rc = dev_alloc(c, &c->d_vl_offsets, ntexels + 2)) || (rc = dev_alloc(c, &c->alt.d_vl_offsets, ntexels + 2))) return rc;
+      c->cap_vl_texels = ntexels + 2;
+    }
+    if (want_refs > c->cap_vl_refs) {
+      c->cap_vl_refs = 0;
+      if ((rc = dev_alloc(c, &c->d_vl_refs, want_refs)) || (rc = dev_alloc(c, &c->alt.d_vl_refs, want_refs))) return rc;
+      c->cap_vl_refs = want_refs;
+      c->cap_vl_nt = 0;  // (the pieces' buffer goes with the references')
+    }
+    const size_t want_nt = std::max(ntexels, (size_t)c->nt) + 2;
+    if (want_nt > c->cap_vl_nt) {
+      c->cap_vl_nt = 0;
+      if ((rc = dev_alloc(c, &c->d_vl_rects, (size_t)c->nt)) || (rc = dev_alloc(c, &c->d_vl_pieces, (size_t)c->nt + 2)) ||
+          (rc = dev_alloc(c, &c->d_vl_piece_tri, c->cap_vl_refs / 64 + (size_t)c->nt + 1)) ||
+          (rc = dev_alloc(c, &c->d_vl_cursor, want_nt)) || (rc = dev_alloc(c, &c->d_vl_totals, want_nt / kScanTile + 2)))
+        return rc;
+      c->cap_vl_nt = want_nt;
+    }
+    return RTGPU_OK;
+  };
+  // (a buffer about to be replaced may still be read by the previous frame's kernels)
+  if (ntexels + 2 > c->cap_vl_texels || want_refs > c->cap_vl_refs || std::max(ntexels, (size_t)c->nt) + 2 > c->cap_vl_nt || !c->d_vl_piece_tri) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(bs));
+    const int rc = grow();
+    if (rc == RTGPU_E_MEMORY) {
+      (void)hipGetLastError();
+      dev_free(&c->d_vl_offsets); dev_free(&c->alt.d_vl_offsets); dev_free(&c->d_vl_refs); dev_free(&c->alt.d_vl_refs);
+      dev_free(&c->d_vl_rects); dev_free(&c->d_vl_pieces); dev_free(&c->d_vl_cursor); dev_free(&c->d_vl_totals); dev_free(&c->d_vl_piece_tri);
+      c->cap_vl_texels = c->cap_vl_refs = c->cap_vl_nt = 0;
+      c->vl_no_memory = true;
+      return RTGPU_OK;
+    }
+    if (rc) return rc;
+  }
+  const int nt = c->nt;
+  const uint32_t cap = (uint32_t)std::min<size_t>(c->cap_vl_refs, 0x7fffffffu);
+  KLAUNCH(c, k_view_rects, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), bs, nt, (const float *)c->d_verts, c->cam, shift, c->d_vl_rects, c->d_vl_pieces);
+  KLAUNCH(c, k_order_scan, dim3(nscan_p), dim3(1024), bs, c->d_vl_pieces, nt + 1, c->d_vl_totals);
+  KLAUNCH(c, k_order_scan_totals, dim3(1), dim3(1024), bs, c->d_vl_totals, nscan_p);
+  KLAUNCH(c, k_ll_starts, dim3((unsigned)((nt + 2 + 255) / 256)), dim3(256), bs, c->d_vl_pieces, (const uint32_t *)c->d_vl_totals, nt + 1, 0u, c->d_vl_cursor);
+  HIPCHK(c, hipMemsetAsync(c->d_vl_offsets, 0, sizeof(uint32_t) * (ntexels + 2), bs));
+  // (every triangle's pieces: at most a 64th of its references, and one)
+  const uint32_t cap_pieces = (uint32_t)std::min<size_t>(c->cap_vl_refs / 64 + (size_t)nt + 1, 0xffffffffu);
+  KLAUNCH(c, k_view_pieces, dim3((unsigned)((nt + 255) / 256)), dim3(256), bs, nt, (const uint32_t *)c->d_vl_pieces, cap_pieces, c->d_vl_piece_tri);
+  const int sblocks = 32 * c->num_cu;
+  KLAUNCH(c, k_view_scatter<false>, dim3(sblocks), dim3(256), bs, (const ViewRectD *)c->d_vl_rects, (const uint32_t *)c->d_vl_pieces, (const int32_t *)c->d_vl_piece_tri,
+          cap_pieces, nt, ntx, (int)ntexels, cap, c->d_vl_offsets, (const uint32_t *)nullptr, (int32_t *)nullptr);
+  KLAUNCH(c, k_order_scan, dim3(nscan_t), dim3(1024), bs, c->d_vl_offsets, (int)ntexels + 1, c->d_vl_totals);
+  KLAUNCH(c, k_order_scan_totals, dim3(1), dim3(1024), bs, c->d_vl_totals, nscan_t);
+  KLAUNCH(c, k_ll_starts, dim3((unsigned)((ntexels + 2 + 255) / 256)), dim3(256), bs, c->d_vl_offsets, (const uint32_t *)c->d_vl_totals, (int)ntexels + 1, 0u, c->d_vl_cursor);
+  KLAUNCH(c, k_view_scatter<true>, dim3(sblocks), dim3(256), bs, (const ViewRectD *)c->d_vl_rects, (const uint32_t *)c->d_vl_pieces, (const int32_t *)c->d_vl_piece_tri,
+          cap_pieces, nt, ntx, (int)ntexels, cap, c->d_vl_cursor, (const uint32_t *)c->d_vl_offsets, c->d_vl_refs);
+  c->vl.offsets = c->d_vl_offsets; c->vl.refs = c->d_vl_refs; c->vl.tri_box = c->d_box; c->vl.cap = cap;
+  c->vl.ntx = ntx; c->vl.nty = nty; c->vl.shift = shift; c->vl.on = 1; c->vl.pad = 0;
+  return RTGPU_OK;
+}
 }  // namespace
 
 int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
@@ -864,6 +957,7 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
       KLAUNCH(c, k_grid_sort, dim3(nonempty), dim3(kSortThreads), bs, g, c->d_nbatch, c->d_recs_unsorted, c->d_recs);
       KLAUNCH(c, k_grid_bounds, dim3(nonempty), dim3(256), bs, g, c->d_nbatch, c->d_hdrs);
     }
+    if ((rc = build_view_lists(c, bs))) return rc;
   }
   if (piped) {
     HIPCHK(c, hipEventRecord(c->ev_built, bs));
@@ -946,13 +1040,18 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
       // A level that neither spawns rays nor meets a textured triangle shades its hits at the end of the walk: the hit
       // records do not go through memory and k_hit is not launched (option "fuse_hit").
       fused = c->opt_fuse_hit && !(L + 1 < c->levels) && c->tex_tri[0] < 0 && c->tex_tri[1] < 0 && c->tex_tri[2] < 0 && c->tex_tri[3] < 0;
+      // the primary rays' hits from the view lists where the frame has them (not the counting variant, which reports the walks)
+      const bool viewed = L == 0 && c->opt_view_lists && c->vl.on && c->filter && !c->opt_count;
       const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued,
-                              c->shade, c->d_nodes, c->d_sorg, (int)c->base[L]};
-#define RT_LAUNCH_NEAREST(COUNT, RECTEST, FUSE) \
-  KLAUNCH(c, (k_nearest<COUNT, RECTEST, FUSE>), dim3(pgrid), dim3(256), c->stream, nargs)
-#define RT_LAUNCH_NEAREST2(COUNT, RECTEST) do { if (fused) RT_LAUNCH_NEAREST(COUNT, RECTEST, true); else RT_LAUNCH_NEAREST(COUNT, RECTEST, false); } while (0)
+                              c->shade, c->d_nodes, c->d_sorg, (int)c->base[L], c->vl};
+#define RT_LAUNCH_NEAREST(COUNT, RECTEST, FUSE, VL) \
+  KLAUNCH(c, (k_nearest<COUNT, RECTEST, FUSE, VL>), dim3(pgrid), dim3(256), c->stream, nargs)
+#define RT_LAUNCH_NEAREST2(COUNT, RECTEST) do { if (fused) RT_LAUNCH_NEAREST(COUNT, RECTEST, true, false); else RT_LAUNCH_NEAREST(COUNT, RECTEST, false, false); } while (0)
+#define RT_LAUNCH_NEAREST3(RECTEST) do { if (fused) RT_LAUNCH_NEAREST(false, RECTEST, true, true); else RT_LAUNCH_NEAREST(false, RECTEST, false, true); } while (0)
       if (c->opt_count) { if (rectest) RT_LAUNCH_NEAREST2(true, true); else RT_LAUNCH_NEAREST2(true, false); }
+      else if (viewed) { if (rectest) RT_LAUNCH_NEAREST3(true); else RT_LAUNCH_NEAREST3(false); }
       else { if (rectest) RT_LAUNCH_NEAREST2(false, true); else RT_LAUNCH_NEAREST2(false, false); }
+#undef RT_LAUNCH_NEAREST3
 #undef RT_LAUNCH_NEAREST2
 #undef RT_LAUNCH_NEAREST
     }
@@ -1397,6 +1496,7 @@ int rtgpu_counters_get(rtgpu_ctx *c, rtgpu_counters *out) {
   out->chunks = c->last_chunks; out->chunks_rerendered = c->last_rerendered;
   out->nearest_full_tests = (int64_t)h[kNearFull]; out->shadow_full_tests = (int64_t)h[kShadFull];
   out->shadow_list_tickets = (int64_t)h[kShadListTickets]; out->shadow_list_fallbacks = (int64_t)h[kShadListFallbacks];
+  out->view_list_tickets = (int64_t)h[kViewListTickets]; out->view_list_fallbacks = (int64_t)h[kViewListFallbacks];
   return RTGPU_OK;
 }
 
@@ -1473,6 +1573,19 @@ int rtgpu_light_list_rects(int32_t nt, const float *verts, int32_t nl, const flo
   if (refs) *refs = (int64_t)h.refs;
   if (faces) memcpy(faces, h.faces.data(), sizeof(LLFaceH) * h.faces.size());  // nl * 12
   if (rects) memcpy(rects, h.rects.data(), sizeof(LLRect) * (size_t)std::min<int64_t>(cap > 0 ? cap : 0, (int64_t)h.rects.size()));
+  return RTGPU_OK;
+}
+
+int rtgpu_view_list_rects(int64_t n, const float *verts, const rtgpu_camera *cams, int64_t ncams, int32_t *out) {
+  if (n < 0 || ncams < 1 || (n > 0 && !verts) || !cams || !out || (ncams != 1 && ncams != n)) return RTGPU_E_INVALID_PARAM;
+  for (int64_t t = 0; t < n; t++) {
+    CameraD cam;
+    memcpy(&cam, cams + (ncams == 1 ? 0 : t), sizeof cam);
+    ViewRect r;
+    int32_t *o = out + 5 * t;
+    o[0] = view_rect(verts + 9 * t, cam, r) ? 1 : 0;
+    o[1] = o[0] ? r.a0 : 0; o[2] = o[0] ? r.a1 : -1; o[3] = o[0] ? r.b0 : 0; o[4] = o[0] ? r.b1 : -1;
+  }
   return RTGPU_OK;
 }
 

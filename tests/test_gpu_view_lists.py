@@ -1,0 +1,132 @@
+"""Primary rays answered from the view lists (option "view_lists") give the frame the cell walks give, bit for bit: the
+reference's nearest-hit walk (src/voxelize.c:536-613) reports the nearest accepted triangle of the first cell that lists
+one before the cell's exit distance; the lists hold every triangle the test can accept for a pixel's ray
+(tests/test_view_lists_cpu.py), and the nearest of those counts only if the ray's own walk passes its distance in a cell
+that lists it."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = [
+    ("scenes/temple/temple", {}, 320, 180),
+    ("scenes/temple/temple", {}, 960, 540),
+    ("scenes/temple/temple", {}, 1001, 333),
+    ("scenes/ulica/ulica", {}, 480, 270),
+    ("scenes/s2/s2", {"atr": "scenes/pokoj/s2.atr"}, 200, 150),
+    ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 800, 600),
+    ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 97, 61),
+]
+
+
+def frame(renderer, scene, lists, rank=0, world=1, **options):
+    renderer.set_option("view_lists", lists)
+    for k, v in options.items():
+        renderer.set_option(k, v)
+    try:
+        renderer.upload(scene)
+        renderer.frame_begin()
+        renderer.counters()  # (totals since the last call)
+        if world == 1:
+            out = renderer.render_host()
+        else:
+            import torch
+            dev = torch.device("cuda:0")
+            n = renderer.tile_count(rank, world) * 64
+            rgb = torch.zeros(n * 3, dtype=torch.float32, device=dev)
+            ids = torch.zeros(n, dtype=torch.int32, device=dev)
+            mm = torch.zeros(6, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(dev)  # the context enqueues on its own stream, which does not wait for torch's zero fill
+            renderer.render(rgb, ids, mm, rank, world)
+            renderer.sync()
+            out = (rgb.cpu().numpy(), ids.cpu().numpy(), mm.cpu().numpy())
+        cnt = renderer.counters().asdict()
+    finally:
+        renderer.set_option("view_lists", 1)
+    return out, cnt
+
+
+@pytest.mark.parametrize("prefix,over,w,h", CASES, ids=["%s_%dx%d" % (c[0].split("/")[1], c[2], c[3]) for c in CASES])
+def test_view_lists_on_and_off_give_the_same_frame(prefix, over, w, h):
+    os.chdir(ROOT)
+    over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+    scene = rt.Scene(os.path.join(ROOT, prefix), width=w, height=h, **over)
+    r = rt.Renderer(0)
+    try:
+        on, con = frame(r, scene, 1)
+        off, coff = frame(r, scene, 0)
+        coarse, ccoarse = frame(r, scene, 1, view_list_texel_shift=3)
+        fine, cfine = frame(r, scene, 1, view_list_texel_shift=0)
+        r.set_option("view_list_texel_shift", 1)
+    finally:
+        r.close()
+    for other in (off, coarse, fine):
+        assert np.array_equal(on["ids"], other["ids"])
+        assert np.array_equal(on["rgb"].view(np.uint32), other["rgb"].view(np.uint32))
+        assert np.array_equal(on["minmax"].view(np.uint32), other["minmax"].view(np.uint32))
+    tiles = ((w + 7) // 8) * ((h + 7) // 8)
+    print("%s %dx%d: %d of %d tickets from the lists, %d fell back to the walk" % (prefix, w, h, con["view_list_tickets"], tiles, con["view_list_fallbacks"]))
+    assert coff["view_list_tickets"] == 0 and coff["view_list_fallbacks"] == 0
+    assert con["view_list_tickets"] + con["view_list_fallbacks"] <= tiles
+    assert con["view_list_tickets"] > 20 * con["view_list_fallbacks"], "the lists answer nearly all tickets"
+    assert ccoarse["view_list_tickets"] > 0 and cfine["view_list_tickets"] > 0
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_scenes_with_the_view_lists(tmp_path, seed):
+    """Generated scenes (tests/scenegen.py: a room of large triangles, boxes, a crowded cluster, slivers; transparent and
+    reflective surfaces; the observer inside the geometry): the frame with the lists equals the frame from the walks and
+    the CPU oracle's (ids and raw colour bit for bit outside pow())."""
+    from oracle import oracle as O
+    from conftest import pow_free_pixels
+    from tests.scenegen import write_scene
+    os.chdir(ROOT)
+    prefix = write_scene(str(tmp_path), seed, 256, 192, opaque=seed % 3 == 0, hard_lights=seed % 2 == 0)
+    scene = rt.Scene(prefix)
+    r = rt.Renderer(0)
+    try:
+        on, con = frame(r, scene, 1)
+        off, coff = frame(r, scene, 0)
+    finally:
+        r.close()
+    assert np.array_equal(on["ids"], off["ids"])
+    assert np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32))
+    assert con["view_list_tickets"] + con["view_list_fallbacks"] > 0 and coff["view_list_tickets"] == 0
+    osc = O.OracleScene(prefix)
+    o = osc.render(shadow_cache=False, threads=1 if osc.npl else 4)
+    assert np.array_equal(on["ids"], o["ids"])
+    clean = o["taint"] == 0
+    exact = pow_free_pixels(scene, o["ids"]) & clean
+    assert np.array_equal(on["rgb"][exact].view(np.uint32), o["rgb"][exact].view(np.uint32))
+    print("seed %d: %d tickets from the lists, %d walked" % (seed, con["view_list_tickets"], con["view_list_fallbacks"]))
+
+
+def test_a_share_of_the_tiles_and_a_moving_camera():
+    """Tiles dealt out round-robin to ranks look their texels up by the tile's place on the screen; the lists are built
+    anew for every frame's camera."""
+    os.chdir(ROOT)
+    scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=640, height=360)
+    r = rt.Renderer(0)
+    try:
+        for rank, world in [(0, 2), (1, 2), (2, 3)]:
+            a, ca = frame(r, scene, 1, rank, world)
+            b, cb = frame(r, scene, 0, rank, world)
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+            assert ca["view_list_tickets"] > 0
+        cam = scene.camera
+        for k in range(3):
+            for q in range(3):  # the observer and the screen move together
+                cam.ob[q] += 0.37; cam.ul[q] += 0.37; cam.ur[q] += 0.37; cam.bl[q] += 0.37
+            on, con = frame(r, scene, 1)
+            off, coff = frame(r, scene, 0)
+            assert np.array_equal(on["ids"], off["ids"])
+            assert np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32))
+            assert con["view_list_tickets"] > 0
+    finally:
+        r.close()

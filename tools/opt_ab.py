@@ -26,5 +26,5 @@ for spec in sys.argv[4:] or [""]:
     r.frame_begin(); r.render_host()
     cn = r.counters().asdict()
     print(spec or "defaults", {k: round(v, 3) for k, v in best.items() if k.endswith("_ms")},
-          {k: cn[k] for k in ("shadow_list_tickets", "shadow_list_fallbacks")}, flush=True)
+          {k: cn[k] for k in ("shadow_list_tickets", "shadow_list_fallbacks", "view_list_tickets", "view_list_fallbacks")}, flush=True)
     r.close()
