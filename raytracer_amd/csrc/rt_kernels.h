@@ -46,6 +46,9 @@ constexpr float kLLFaceExt = 1.25f;  // (rt_lightlists.h: kFaceExt)
 #ifndef RT_WAVES_ENDS
 #define RT_WAVES_ENDS 7  // ... and its instances for rays that end at their lights (scenes with secondary rays): ulica 1080p 105 -> 101 ms with seven (72 VGPRs), where temple's instance loses 6 %
 #endif
+#ifndef RT_WAVES_VIEW
+#define RT_WAVES_VIEW 5  // ... and its instance that answers the primary rays from the view lists
+#endif
 #ifndef RT_WAVES_NEAREST
 #define RT_WAVES_NEAREST 5  // ... and the nearest-hit walk: it keeps more per ray (the best hit), 96 VGPRs hold it without spills (4 % faster than 6 waves)
 #endif
@@ -1371,7 +1374,9 @@ __global__ void __launch_bounds__(256) k_grid_bounds(GridP g, const uint32_t *__
 // costs an LDS read instead of a trip to L2 per step.
 constexpr int kOccWords = 1536;
 // Copies the occupancy map into the block's LDS if it fits; returns whether it did.
-RT_D bool load_occupancy(const GridP &g, uint32_t *occ_s) {
+// occ_box_s: the kernel's copy of the box of the non-empty cells (g.occ_box), for walk_init.
+RT_D bool load_occupancy(const GridP &g, uint32_t *occ_s, int32_t *occ_box_s) {
+  if (threadIdx.x < 6) occ_box_s[threadIdx.x] = g.occ_box[threadIdx.x];
   const bool fits = g.ncells <= kOccWords * 32;
   if (fits)
     for (int i = threadIdx.x; i * 32 < g.ncells; i += blockDim.x) occ_s[i] = g.occ[i];
@@ -1533,9 +1538,10 @@ RT_D bool apex_slabs_pass(const RecA &A, f3 ab, f3 P, float an, float kc_max, f3
   return !(out | behind);
 }
 // in: the lanes whose rays take part (all with the origin o); beg .. end: the texel's references
+constexpr int kViewSlotFloats = 32;
 template <typename T>
 RT_D void view_candidates(const GridP &g, const int32_t *__restrict__ refs, uint32_t beg, uint32_t end, bool in, f3 o, f3 r, float onorm,
-                          float *slice, int lane, uint32_t (&diag)[3], T &&test) {
+                          float *slice, int lane, uint32_t (&diag)[3], Phases &ph, T &&test) {
   const int mid = central_lane(in, lane, true, 0);
   const f3 axis = lane_bcast3(r, mid), o_all = lane_bcast3(o, mid);
   const f3 dr = sub3(r, axis);
@@ -1545,13 +1551,17 @@ RT_D void view_candidates(const GridP &g, const int32_t *__restrict__ refs, uint
   float on_own = in ? onorm : 0.0f;
   if (!(on_own >= 0.0f)) on_own = INFINITY;
   const float onorm_all = lane_bcast(wave_max(on_own), 0);
-  constexpr int kSlots = kSliceFloats / kRecFloats;  // records of the slice for a pass's survivors
-  static_assert(kSlots >= 32, "most passes fit the slice at once");
+  // a survivor's slot in the slice: its record, then i, ij, ik for the exact test (so that no test waits for memory)
+  constexpr int kSlots = kSliceFloats / kViewSlotFloats;
+  static_assert(kSlots >= 24 && kViewSlotFloats % 4 == 0 && kViewSlotFloats >= kRecFloats + 9, "most passes fit the slice at once; records stay 16-byte aligned");
   for (uint32_t e0 = beg; e0 < end; e0 += 64u) {
     bool pass = false;
     const v4f *R = nullptr;
+    const float *G = nullptr;
     if (e0 + (uint32_t)lane < end) {
-      R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)refs[e0 + lane]);
+      const int id = refs[e0 + lane];
+      R = reinterpret_cast<const v4f *>(g.filt + (size_t)kRecFloats * (size_t)id);
+      G = g.geom + 9 * (size_t)id;
       const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
       RecA A; A.n = mk3(r0.x, r0.y, r0.z); A.ac = mk3(r1.x, r1.y, r1.z); A.q = mk3(r1.w, r2.x, r2.y);
       const float kc_max = __builtin_fmaf(r0.w, onorm_all, r2.w) + g.slack;
@@ -1559,21 +1569,28 @@ RT_D void view_candidates(const GridP &g, const int32_t *__restrict__ refs, uint
     }
     diag[1] += (uint32_t)__popcll(__ballot(e0 + (uint32_t)lane < end));
     unsigned long long todo = __ballot(pass);
+    ph.end<3, true>();
     while (todo != 0) {
       const int before = __popcll(todo & lanes_below(lane));
       const bool mine = ((todo >> lane) & 1ull) != 0 && before < kSlots;
       if (mine) {
-        v4f *D = reinterpret_cast<v4f *>(slice + before * kRecFloats);
+        v4f *D = reinterpret_cast<v4f *>(slice + before * kViewSlotFloats);
         const v4f r0 = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4];
+        const float g0 = G[0], g1 = G[1], g2 = G[2], g3 = G[3], g4 = G[4], g5 = G[5], g6 = G[6], g7 = G[7], g8 = G[8];
         D[0] = r0; D[1] = r1; D[2] = r2; D[3] = r3; D[4] = r4;
+        v4f x; x.x = g0; x.y = g1; x.z = g2; x.w = g3; D[5] = x;
+        x.x = g4; x.y = g5; x.z = g6; x.w = g7; D[6] = x;
+        slice[before * kViewSlotFloats + 28] = g8;
       }
       const unsigned long long placed = __ballot(mine);
       todo &= ~placed;
       __builtin_amdgcn_wave_barrier();
       const int n = __popcll(placed);
       diag[2] += (uint32_t)n;
-      for (int q2 = 0; q2 < n; q2++) test(slice + q2 * kRecFloats);
+      ph.end<4, true>();
+      for (int q2 = 0; q2 < n; q2++) test(slice + q2 * kViewSlotFloats);
       __builtin_amdgcn_wave_barrier();
+      ph.end<5, true>();
     }
   }
 }
@@ -1622,7 +1639,7 @@ struct NearestArgs {
 };
 // VL: the tickets of primary rays are answered from the view lists where they can be (view_candidates, view_verify)
 template <bool COUNT, bool RECTEST, bool FUSE, bool VL = false>
-__global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs args) {
+__global__ void __launch_bounds__(256, VL ? RT_WAVES_VIEW : RT_WAVES_NEAREST) k_nearest(NearestArgs args) {
   static_assert(!VL || !COUNT, "the counting variant reports the reference's walks");
   const GridP &g = args.g;
   const Ray *__restrict__ rays = args.rays;
@@ -1633,7 +1650,8 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
-  const bool occ_in_lds = load_occupancy(g, occ_s);
+  __shared__ int32_t occ_box_s[8];
+  const bool occ_in_lds = load_occupancy(g, occ_s, occ_box_s);
   const int lane = lane_id();
   const int nrays = queue_len(ctl, level);
   const uint32_t *__restrict__ cstart = g.cell_start;
@@ -1701,7 +1719,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
       const uint32_t *__restrict__ cstart = g.cell_start;
       if (COUNT) nQ++;
       const int glo[3] = {0, 0, 0}, ghi[3] = {g.nv[0] - 1, g.nv[1] - 1, g.nv[2] - 1};
-      walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, !COUNT, w);  // (the counting variant reports the reference's step counts)
+      walk_init(g, o, r, ry.i, ry.j, ry.k, glo, ghi, !COUNT, occ_box_s, w);  // (the counting variant reports the reference's step counts)
       // stand on the first non-empty cell of the walk (the start voxel counts as visited)
       if (COUNT) nS++;
       if (!VL) {
@@ -1728,14 +1746,31 @@ __global__ void __launch_bounds__(256, RT_WAVES_NEAREST) k_nearest(NearestArgs a
           nViewFell++;
           float best = INFINITY, best_u = 0.0f, best_v = 0.0f;
           int best_id = -1;
-          uint32_t nopos = 0;
           uint32_t diag[3] = {0u, 0u, 0u};
-          view_candidates(g, vl.refs, lbeg, lend, alive, o, r, onorm, slice, lane, diag, [&](const float *R) {
+          ph.end<1>();
+          // (the walk's test with the triangle's i, ij, ik read from the slot instead of from memory)
+          view_candidates(g, vl.refs, lbeg, lend, alive, o, r, onorm, slice, lane, diag, ph, [&](const float *R) {
             const float kc = alive ? __builtin_fmaf(R[3], onorm, R[11]) + g.slack : -INFINITY;
-            test(R, o, r, pm, kc, ry.current, best, best_id, best_u, best_v, 0u, nopos);
+            const RecA A = rec_a(R);
+            PlTest t;
+            const bool p1 = pl_stage1(A.n, A.ac, A.q, r, pm, kc, t);
+            if (wave_any(p1)) {
+              asm volatile("; some lane passed the first slab");
+              bool s3 = false, ex = false;
+              if (p1) ex = nearest_needs_exact(R, A, t, o, r, pm, kc, g.lmax, best, s3);
+              if (ex) {
+                const int id = rec_id(R);
+                float d, u, v;
+                if (tri_test(ld3(R + kRecFloats), ld3(R + kRecFloats + 3), ld3(R + kRecFloats + 6), o, r, d, u, v) && id != ry.current &&
+                    (d < best || (d == best && id < best_id))) { best = d; best_id = id; best_u = u; best_v = v; }
+              }
+            }
           });
           Walk v = w;
-          if (view_verify(g, vl.tri_box, alive && best_id >= 0, best_id, best, r, ry.i, ry.j, ry.k, v)) {
+          ph.end<5>();
+          const bool agreed = view_verify(g, vl.tri_box, alive && best_id >= 0, best_id, best, r, ry.i, ry.j, ry.k, v);
+          ph.end<6>();
+          if (agreed) {
             if (alive && best_id >= 0) { h.tri = best_id; h.d = best; h.u = best_u; h.v = best_v; w = v; }
             alive = false;
             nViewed++; nViewFell--;
@@ -2480,7 +2515,8 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
   __shared__ __attribute__((aligned(16))) float lds_batches[4][kSliceFloats];
   __shared__ uint32_t occ_s[kOccWords];
   float *slice = lds_batches[threadIdx.x >> 6];
-  const bool occ_in_lds = load_occupancy(g, occ_s);
+  __shared__ int32_t occ_box_s[8];
+  const bool occ_in_lds = load_occupancy(g, occ_s, occ_box_s);
   const int lane = lane_id();
   const int n = queue_len(ctl, level);
   const long long total = (long long)n * sp.nslots;
@@ -2550,7 +2586,7 @@ __global__ void __launch_bounds__(256, ENDS ? RT_WAVES_ENDS : LL ? RT_WAVES_LL :
             int lo[3], hi[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { lo[c] = ai[c] < bi[c] ? ai[c] : bi[c]; hi[c] = ai[c] < bi[c] ? bi[c] : ai[c]; }
-            walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, !COUNT, w);
+            walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, !COUNT, occ_box_s, w);
             pl_ray(a, r, pm, onorm, odr);
             alive = true;
             if (COUNT) { nW++; nS++; }
@@ -2830,6 +2866,9 @@ __global__ void __launch_bounds__(256, RT_WAVES_LISTS) k_shadow_lists(ListsArgs 
   const int lane = lane_id();
   const GridP &g = args.g;
   const LightListsP &ll = args.ll;
+  __shared__ int32_t occ_box_s[8];
+  if (threadIdx.x < 6) occ_box_s[threadIdx.x] = g.occ_box[threadIdx.x];
+  __syncthreads();
   const int n = queue_len(args.ctl, 0);
   uint32_t nListed = 0, nDeferred = 0;
   Tickets tickets((unsigned long long)n);
@@ -2893,7 +2932,7 @@ __global__ void __launch_bounds__(256, RT_WAVES_LISTS) k_shadow_lists(ListsArgs 
               int lo[3], hi[3];
 #pragma unroll
               for (int c = 0; c < 3; c++) { lo[c] = ai[c] < bi[c] ? ai[c] : bi[c]; hi[c] = ai[c] < bi[c] ? bi[c] : ai[c]; }
-              walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, true, v);
+              walk_init(g, a, r, ai[0], ai[1], ai[2], lo, hi, true, occ_box_s, v);
               vi = ai[0]; vj = ai[1]; vk = ai[2];
             })) {
           if (alive && hit_id >= 0) result = -1.0f;

@@ -197,12 +197,13 @@ struct Walk {
 };
 // clamp: the range is cut down to the box of the non-empty cells; a walk that leaves that box meets no triangle
 // any more (each axis moves one way only), so ending it there changes no result, only the number of steps.
-RT_D void walk_init(const GridP &g, f3 o, f3 r, int i, int j, int k, const int lo_[3], const int hi_[3], bool clamp, Walk &w) {
+// occ_box: that box, lo[3] then hi[3] (g.occ_box, or the kernel's copy of it in LDS: one trip to memory less per ticket).
+RT_D void walk_init(const GridP &g, f3 o, f3 r, int i, int j, int k, const int lo_[3], const int hi_[3], bool clamp, const int32_t *occ_box, Walk &w) {
   int lo[3] = {lo_[0], lo_[1], lo_[2]}, hi[3] = {hi_[0], hi_[1], hi_[2]};
   if (clamp) {
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-      const int ol = g.occ_box[q], oh = g.occ_box[3 + q];
+      const int ol = occ_box[q], oh = occ_box[3 + q];
       lo[q] = lo[q] > ol ? lo[q] : ol;
       hi[q] = hi[q] < oh ? hi[q] : oh;
     }

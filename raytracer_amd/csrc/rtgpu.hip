@@ -1042,6 +1042,7 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
       fused = c->opt_fuse_hit && !(L + 1 < c->levels) && c->tex_tri[0] < 0 && c->tex_tri[1] < 0 && c->tex_tri[2] < 0 && c->tex_tri[3] < 0;
       // the primary rays' hits from the view lists where the frame has them (not the counting variant, which reports the walks)
       const bool viewed = L == 0 && c->opt_view_lists && c->vl.on && c->filter && !c->opt_count;
+      const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * (viewed ? RT_WAVES_VIEW : RT_WAVES_NEAREST)) + 3) / 4);
       const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued,
                               c->shade, c->d_nodes, c->d_sorg, (int)c->base[L], c->vl};
 #define RT_LAUNCH_NEAREST(COUNT, RECTEST, FUSE, VL) \

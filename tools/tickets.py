@@ -62,6 +62,7 @@ def main():
         cyc = log[:, 0]
         print("%s walk %.3f ms: %d tickets, clocks mean %.0f, median %.0f, p99 %.0f, max %d (%.1f x mean); sum/8192 waves = %.0f"
               % (kind, t[kind + "_ms"], len(log), cyc.mean(), np.median(cyc), np.quantile(cyc, 0.99), cyc.max(), cyc.max() / cyc.mean(), cyc.sum() / 8192))
+        print("   per ticket: visits %.1f, batches (view / light lists: references read) %.1f, records tested %.1f" % (log[:, 1].mean(), log[:, 2].mean(), log[:, 3].mean()))
         if log[:, 4:].sum() > 0:
             ph = log[:, 4:].sum(0)
             print("   all tickets, share of the phases (set-up, mode, headers+cos, culling, record staging, tests, stepping, lane/ray mode): "
