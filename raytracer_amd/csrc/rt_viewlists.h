@@ -2,7 +2,8 @@
 // through the grid (voxelize.c:536-613).  The screen is cut into texels of 8 x 8 pixels (one tile of the kernels) or a
 // power of two times that, and a texel lists every triangle that the exact test (intersection.c:58-86) can accept for
 // the ray of one of its pixels.  Built per frame on the device (the camera may move from frame to frame): view_rect gives
-// a triangle's rectangle of pixels, in double precision; k_view_count / k_view_fill make the lists; k_nearest reads them.
+// a triangle's rectangle of pixels, in double precision; k_view_rects, k_view_pieces and k_view_scatter make the lists;
+// k_nearest's VL instance reads them.
 // The same idea as the light lists (rt_lightlists.h) with the observer in the light's place.
 //
 // What has to hold.  The ray of pixel (px, py) is o = ob, r = normalize(fl(dir)) with dir = ul - ob + (px / w) (ur - ul) +
