@@ -9,10 +9,11 @@ rtVisualizedSceneToBitmap do: per-triangle preprocess, grid build, primary rays,
 shading with one shadow query per (hit, light), global min/max, tone map to RGBA8, and with N>1 the
 min/max all-reduce and the RGBA8 tile gather to rank 0 (RCCL).  The scene is uploaded to HBM before
 the timed region; the finished image stays in HBM on rank 0.  The frame is split by 8x8 tiles over
-the ranks, so total work is fixed as N grows ("strong" scaling).  With N > 1 two frames are in flight on every GPU
+the ranks, so total work is fixed as N grows ("strong" scaling).  Two frames are in flight on every GPU
 (raytracer_amd.dist.FramePipeline: each in its own context and stream; a frame's exchange and the latency-bound end of
-its walk kernels run under the other frame's kernels; one GPU renders one frame at a time, so that a kernel's launch time
-is its own); all K frames are complete when the timed region ends, and ms_per_step is the region's length / K.
+its walk kernels run under the other frame's kernels); all K frames are complete when the timed region ends, and
+ms_per_step is the region's length / K.  On one GPU the line also carries one_frame_at_a_time: the same workload with one
+frame in flight, where a kernel's launch time is its own (value, ms_per_step, kernel times and roofline of that run).
 config.frames_in_flight says how many, --frames-in-flight overrides; frame_latency_ms is one frame alone, start to
 finish (barriers included).
 
@@ -322,7 +323,7 @@ def main():
     ap.add_argument("--scene", default="temple")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 1 on one GPU, 2 on several")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 2 for the headline workload, and for the config5 legs 1 on one GPU, 2 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-width", type=int, default=960)
     ap.add_argument("--cpu-height", type=int, default=540)
@@ -366,16 +367,27 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     env = {"torch": torch, "dist": dist, "rt": rt, "dev": dev, "rank": rank, "world": world, "local_rank": local_rank}
-    # Frames in flight on this rank's GPU (FramePipeline): one on a single GPU, two where a rank renders a share of the frame
-    depth = args.frames_in_flight if args.frames_in_flight > 0 else default_depth(world)
+    # Frames in flight on this rank's GPU (FramePipeline): two for the headline workload whatever N (the latency-bound end of a
+    # frame's walk kernels runs under the next frame's; the same setting for every N, so that the values compare), and what
+    # dist.default_depth says for the config5 legs (one on a single GPU: ulica's frames fill it by themselves)
+    depth = args.frames_in_flight if args.frames_in_flight > 0 else 2
+    leg_depth = args.frames_in_flight if args.frames_in_flight > 0 else default_depth(world)
     main_leg = run_leg(env, args.scene, args.width, args.height, args.steps, args.warmup, depth)
+    # ... and the same workload one frame at a time on a single GPU: a kernel's launch time is then its own (the counter
+    # profiles under profiles/ are taken that way)
+    alone_leg = None
+    if world == 1 and depth > 1:
+        try:
+            alone_leg = run_leg(env, args.scene, args.width, args.height, args.steps, args.warmup, 1, 0)
+        except Exception as e:
+            alone_leg = {"error": str(e)}
     # Config 5 of the baseline (scenes/ulica at 7680x4320, maximum depth: the divergence stress) beside the headline
     # workload, with its own rooflines: 1920x1080 (three frames) and the full 7680x4320 (one frame), same ranks, same exchange.
     legs = {}
     if not args.no_config5 and args.scene == "temple":
         for name, w, h, k, wu, reps in (("ulica_1920x1080", 1920, 1080, 3, 1, 1), ("ulica_7680x4320", 7680, 4320, 1, 1, 0)):
             try:
-                legs[name] = run_leg(env, "ulica", w, h, k, wu, depth, reps)
+                legs[name] = run_leg(env, "ulica", w, h, k, wu, leg_depth, reps)
             except Exception as e:  # an extra of the line: never a reason to lose the headline number
                 legs[name] = {"error": str(e)}
 
@@ -387,12 +399,25 @@ def main():
                "kernel_ms_per_frame_rank0": main_leg["kernel_ms_per_frame_rank0"],
                "setup_ms_on_build_stream_rank0": main_leg["setup_ms_on_build_stream_rank0"],
                "kernel_ms_note": "HIP events on the stream each kernel runs on: nearest_ms and shadow_ms over the timed frames, the others "
-                                 "over the warm-up frames (the events of every kernel cost 0.07 ms per frame); kernel_ms_per_frame_rank0 sums to the frame. "
+                                 "over the warm-up frames (the events of every kernel cost 0.07 ms per frame); with one frame in flight kernel_ms_per_frame_rank0 sums to the frame. "
                                  "setup_ms_on_build_stream_rank0 is the set-up of frame k+1 (preprocess, grid build: 0.27 ms alone) as it elapses on the build "
                                  "stream UNDER the walk kernels of frame k, where it waits for free compute units: not part of the frame's critical path"
                                  + ("; with %d frames in flight a kernel shares the GPU with the other frame's, so these are longer than "
                                     "the kernel alone" % depth if depth > 1 else ""),
                "roofline": main_leg["roofline"], "walk_stats_rank0": main_leg["walk_stats_rank0"]}
+        if alone_leg is not None and "error" not in alone_leg:
+            # The roofline object prices the dominant kernel by ITS OWN launch time: the K timed frames of the one-frame-at-a-time
+            # leg of this run (the counter profiles and the kernel trace under profiles/ are taken the same way, --frames-in-flight 1).
+            # Beside another frame's kernels the same launch lasts longer while the GPU does more per unit of time.
+            roof = dict(alone_leg["roofline"])
+            roof["avg_launch_ms_two_in_flight"] = main_leg["roofline"]["avg_launch_ms"]
+            roof["timed_region"] = ("the %d timed frames of this run's one_frame_at_a_time leg (one frame in flight: the kernel has the GPU to "
+                                    "itself); with %d frames in flight, as `value` is measured, the launch shares the GPU with the other frame's "
+                                    "kernels and lasts avg_launch_ms_two_in_flight" % (alone_leg["steps"], depth))
+            out["roofline"] = roof
+        if alone_leg is not None:
+            out["one_frame_at_a_time"] = alone_leg if "error" in alone_leg else {
+                k: alone_leg[k] for k in ("value", "unit", "steps", "ms_per_step", "kernel_ms_per_frame_rank0", "setup_ms_on_build_stream_rank0", "roofline")}
         if legs:
             out["config5"] = legs
         if world == 1 and not args.no_cpu_baseline:

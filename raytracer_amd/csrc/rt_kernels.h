@@ -2109,13 +2109,15 @@ __global__ void __launch_bounds__(256) k_view_scatter(const ViewRectD *__restric
   const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
   for (uint32_t W = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); W < total; W += nwaves) {
     const int t = piece_tri[W];
+    if ((unsigned)t >= (unsigned)nt) continue;  // (cannot happen while the pieces' scan holds; a stray entry must not become an address)
     const ViewRectD r = rects[t];
     const uint32_t a0 = r.ab & 0xffffu, a1 = r.ab >> 16, b0 = r.cd & 0xffffu, b1 = r.cd >> 16;
     const uint32_t nw = a1 - a0 + 1u, cells = nw * (b1 - b0 + 1u);
     const uint32_t e = (W - piece_start[t]) * 64u + (uint32_t)lane;
     if (e < cells) {
       const uint32_t texel = (b0 + e / nw) * (uint32_t)ntx + a0 + e % nw;
-      if (FILL) refs[atomicAdd(&counts_or_cursor[texel], 1u)] = t;
+      if (texel >= (uint32_t)ntexels) continue;
+      if (FILL) { const uint32_t at = atomicAdd(&counts_or_cursor[texel], 1u); if (at < cap) refs[at] = t; }
       else atomicAdd(&counts_or_cursor[texel], 1u);
     }
   }

@@ -164,6 +164,7 @@ struct rtgpu_ctx {
   uint32_t *d_ll_deferred = nullptr;  // (ticket, light) pairs k_shadow_lists leaves to k_shadow (one of the chunk's queues)
   // view lists (rt_viewlists.h): built with every frame's set-up; offsets and references belong to the frame's set (alt: the other set's)
   bool opt_view_lists = true;  // option "view_lists"
+  int64_t opt_vl_capacity = 0; // option "view_list_capacity": room for that many references instead of the planned number (0); for tests
   int opt_vl_shift = 1;        // option "view_list_texel_shift": a texel is at least 2^shift tiles a side (temple 3840x2160: 2.11, 2.04, 2.03 ms a frame with 0, 1, 2)
   ViewListsP vl = {};
   uint32_t *d_vl_offsets = nullptr, *d_vl_pieces = nullptr, *d_vl_cursor = nullptr, *d_vl_totals = nullptr;
@@ -528,6 +529,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
   else if (!strcmp(name, "view_lists")) c->opt_view_lists = value != 0;
+  else if (!strcmp(name, "view_list_capacity")) { if (value < 0 || value > (1ll << 30)) return fail(c, RTGPU_E_INVALID_PARAM, "view_list_capacity: 0 (planned) .. 2^30"); c->opt_vl_capacity = value; }
   else if (!strcmp(name, "view_list_texel_shift")) { if (value < 0 || value > 4) return fail(c, RTGPU_E_INVALID_PARAM, "view_list_texel_shift: 0..4"); c->opt_vl_shift = (int)value; }
   else if (!strcmp(name, "light_list_kernel")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_kernel: 0, 1 or 2"); c->opt_ll_kernel = (int)value; }
   else if (!strcmp(name, "light_list_levels")) {
@@ -779,6 +781,8 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
   const int ntx = ((tiles_x - 1) >> shift) + 1, nty = ((tiles_y - 1) >> shift) + 1;
   if (ntx > 65535 || nty > 65535 || (int64_t)ntx * nty > (1 << 18)) return RTGPU_OK;
   const size_t ntexels = (size_t)ntx * nty;
+  // (the pieces of all rectangles are numbered in 32 bits: a scene of so many triangles that they could not be keeps its walks)
+  if ((uint64_t)c->nt * ((ntexels + 63) / 64 + 1) >= (1ull << 32)) return RTGPU_OK;
   const size_t want_refs = std::max<size_t>((size_t)1 << 20, 64 * ntexels + 16 * (size_t)c->nt);
   const int nscan_t = (int)((ntexels + 1 + kScanTile - 1) / kScanTile), nscan_p = (int)(((size_t)c->nt + 1 + kScanTile - 1) / kScanTile);
   auto grow = [&]() -> int {
@@ -799,6 +803,7 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
       c->cap_vl_nt = 0;
       if ((rc = dev_alloc(c, &c->d_vl_rects, (size_t)c->nt)) || (rc = dev_alloc(c, &c->d_vl_pieces, (size_t)c->nt + 2)) ||
           (rc = dev_alloc(c, &c->d_vl_piece_tri, c->cap_vl_refs / 64 + (size_t)c->nt + 1)) ||
+          (hipMemset(c->d_vl_piece_tri, 0, sizeof(int32_t) * (c->cap_vl_refs / 64 + (size_t)c->nt + 1)) != hipSuccess ? (rc = RTGPU_E_MEMORY) : 0) ||
           (rc = dev_alloc(c, &c->d_vl_cursor, want_nt)) || (rc = dev_alloc(c, &c->d_vl_totals, want_nt / kScanTile + 2)))
         return rc;
       c->cap_vl_nt = want_nt;
@@ -821,7 +826,7 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
     if (rc) return rc;
   }
   const int nt = c->nt;
-  const uint32_t cap = (uint32_t)std::min<size_t>(c->cap_vl_refs, 0x7fffffffu);
+  const uint32_t cap = (uint32_t)std::min<size_t>(c->opt_vl_capacity > 0 ? std::min<size_t>((size_t)c->opt_vl_capacity, c->cap_vl_refs) : c->cap_vl_refs, 0x7fffffffu);
   KLAUNCH(c, k_view_rects, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), bs, nt, (const float *)c->d_verts, c->cam, shift, c->d_vl_rects, c->d_vl_pieces);
   KLAUNCH(c, k_order_scan, dim3(nscan_p), dim3(1024), bs, c->d_vl_pieces, nt + 1, c->d_vl_totals);
   KLAUNCH(c, k_order_scan_totals, dim3(1), dim3(1024), bs, c->d_vl_totals, nscan_p);

@@ -130,3 +130,22 @@ def test_a_share_of_the_tiles_and_a_moving_camera():
             assert con["view_list_tickets"] > 0
     finally:
         r.close()
+
+
+def test_a_frame_whose_lists_do_not_fit_their_buffer_walks():
+    """The references of a frame's lists are counted before they are written; with room for fewer (option
+    "view_list_capacity", there for this test) nothing is written and every ticket walks: same frame."""
+    os.chdir(ROOT)
+    scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=640, height=360)
+    r = rt.Renderer(0)
+    try:
+        full, cfull = frame(r, scene, 1)
+        small, csmall = frame(r, scene, 1, view_list_capacity=1000)
+        again, cagain = frame(r, scene, 1, view_list_capacity=0)
+    finally:
+        r.close()
+    for other in (small, again):
+        assert np.array_equal(full["ids"], other["ids"])
+        assert np.array_equal(full["rgb"].view(np.uint32), other["rgb"].view(np.uint32))
+    assert cfull["view_list_tickets"] > 0 and cagain["view_list_tickets"] == cfull["view_list_tickets"]
+    assert csmall["view_list_tickets"] == 0 and csmall["view_list_fallbacks"] == 0

@@ -22,9 +22,10 @@ counters temple 3840 2160 "" || exit 1
 counters ulica 1920 1080 _ulica1080 || exit 1
 counters ulica 7680 4320 _ulica8k || exit 1
 timeout -k 10 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { tail -5 gpurun_out/${TAG}_bench.err; exit 1; }
-# kernel traces, one workload per run (the statistics are per kernel name)
-(cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-config5 > $ROOT/gpurun_out/${TAG}_trace.log 2>&1) || { tail -5 gpurun_out/${TAG}_trace.log; exit 1; }
-(cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_trace_ulica1080 -- python3 $ROOT/bench.py --no-cpu-baseline --scene ulica --width 1920 --height 1080 --steps 3 --warmup 1 > $ROOT/gpurun_out/${TAG}_trace_ulica1080.log 2>&1) || { tail -5 gpurun_out/${TAG}_trace_ulica1080.log; exit 1; }
+# kernel traces, one workload per run (the statistics are per kernel name), one frame in flight (a kernel's time is its own:
+# what the bench line's roofline object is priced with)
+(cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-config5 --frames-in-flight 1 > $ROOT/gpurun_out/${TAG}_trace.log 2>&1) || { tail -5 gpurun_out/${TAG}_trace.log; exit 1; }
+(cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_trace_ulica1080 -- python3 $ROOT/bench.py --no-cpu-baseline --scene ulica --width 1920 --height 1080 --steps 3 --warmup 1 --frames-in-flight 1 > $ROOT/gpurun_out/${TAG}_trace_ulica1080.log 2>&1) || { tail -5 gpurun_out/${TAG}_trace_ulica1080.log; exit 1; }
 # (large per-dispatch tables are not needed back: keep the statistics)
 find gpurun_out -name "*kernel_trace.csv" -size +2M -delete
 echo profile round $TAG done
