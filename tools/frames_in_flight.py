@@ -63,8 +63,8 @@ def run(wd, k, mode, wpc=0):
 
 
 for wd in [int(x) for x in os.environ.get("RT_WORLDS", "1,%d" % world).split(",")]:
-    for k in (1, 2, 3):
-        for mode in ("free", "stagger"):
+    for k in [int(x) for x in os.environ.get("RT_DEPTHS", "1,2,3").split(",")]:
+        for mode in os.environ.get("RT_MODES", "free,stagger").split(","):
             if k == 1 and mode == "stagger":
                 continue
             for wpc in [int(x) for x in os.environ.get("RT_WPC", "0").split(",")]:
