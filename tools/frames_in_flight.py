@@ -28,6 +28,9 @@ def run(wd, k, mode, wpc=0):
         r = rt.Renderer(0)
         if wpc:
             r.set_option("waves_per_cu", wpc)
+        for kv in os.environ.get("RT_OPTIONS", "").split(","):  # e.g. RT_OPTIONS=view_lists=0
+            if "=" in kv:
+                r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         r.upload(scene)
         s = torch.cuda.Stream(dev)
         r.set_stream(s)
