@@ -176,7 +176,7 @@ struct ViewListsP {
   const int32_t *tri_box;  // per triangle the voxel index box lo[3], hi[3] of this frame's grid
   uint32_t cap;
   int32_t ntx, nty, shift, on;
-  int32_t pad;
+  int32_t pad;  // (not 0: every other ticket is treated as if its walks had not confirmed the lists' answer; for tests)
 };
 
 // Device-side control block of one chunk: queue lengths and statistics (the allocation continues with the ticket counters

@@ -164,6 +164,7 @@ struct rtgpu_ctx {
   uint32_t *d_ll_deferred = nullptr;  // (ticket, light) pairs k_shadow_lists leaves to k_shadow (one of the chunk's queues)
   // view lists (rt_viewlists.h): built with every frame's set-up; offsets and references belong to the frame's set (alt: the other set's)
   bool opt_view_lists = true;  // option "view_lists"
+  bool opt_vl_test_fallback = false;  // option "view_list_test_fallback": every other ticket walks after its lookup, as if the walks had not confirmed it; for tests
   int64_t opt_vl_capacity = 0; // option "view_list_capacity": room for that many references instead of the planned number (0); for tests
   int opt_vl_shift = 1;        // option "view_list_texel_shift": a texel is at least 2^shift tiles a side (temple 3840x2160: 2.11, 2.04, 2.03 ms a frame with 0, 1, 2)
   ViewListsP vl = {};
@@ -529,6 +530,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
   else if (!strcmp(name, "view_lists")) c->opt_view_lists = value != 0;
+  else if (!strcmp(name, "view_list_test_fallback")) c->opt_vl_test_fallback = value != 0;
   else if (!strcmp(name, "view_list_capacity")) { if (value < 0 || value > (1ll << 30)) return fail(c, RTGPU_E_INVALID_PARAM, "view_list_capacity: 0 (planned) .. 2^30"); c->opt_vl_capacity = value; }
   else if (!strcmp(name, "view_list_texel_shift")) { if (value < 0 || value > 4) return fail(c, RTGPU_E_INVALID_PARAM, "view_list_texel_shift: 0..4"); c->opt_vl_shift = (int)value; }
   else if (!strcmp(name, "light_list_kernel")) { if (value < 0 || value > 2) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_kernel: 0, 1 or 2"); c->opt_ll_kernel = (int)value; }
@@ -844,7 +846,7 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
   KLAUNCH(c, k_view_scatter<true>, dim3(sblocks), dim3(256), bs, (const ViewRectD *)c->d_vl_rects, (const uint32_t *)c->d_vl_pieces, (const int32_t *)c->d_vl_piece_tri,
           cap_pieces, nt, ntx, (int)ntexels, cap, c->d_vl_cursor, (const uint32_t *)c->d_vl_offsets, c->d_vl_refs);
   c->vl.offsets = c->d_vl_offsets; c->vl.refs = c->d_vl_refs; c->vl.tri_box = c->d_box; c->vl.cap = cap;
-  c->vl.ntx = ntx; c->vl.nty = nty; c->vl.shift = shift; c->vl.on = 1; c->vl.pad = 0;
+  c->vl.ntx = ntx; c->vl.nty = nty; c->vl.shift = shift; c->vl.on = 1; c->vl.pad = c->opt_vl_test_fallback ? 1 : 0;
   return RTGPU_OK;
 }
 }  // namespace

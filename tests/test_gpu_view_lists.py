@@ -149,3 +149,67 @@ def test_a_frame_whose_lists_do_not_fit_their_buffer_walks():
         assert np.array_equal(full["rgb"].view(np.uint32), other["rgb"].view(np.uint32))
     assert cfull["view_list_tickets"] > 0 and cagain["view_list_tickets"] == cfull["view_list_tickets"]
     assert csmall["view_list_tickets"] == 0 and csmall["view_list_fallbacks"] == 0
+
+
+@pytest.mark.parametrize("name,prefix,over", [("temple", "scenes/temple/temple", {}), ("ulica", "scenes/ulica/ulica", {})])
+def test_cameras_anywhere_in_the_scene_looking_anywhere(name, prefix, over):
+    """Sixteen cameras at random places inside the scene's box (also inside its geometry, on its surfaces' planes, a hair
+    from a vertex), looking in random directions with random fields of view: the frame with the lists is the frame from
+    the walks."""
+    os.chdir(ROOT)
+    w, h = 240, 136
+    scene = rt.Scene(os.path.join(ROOT, prefix), width=w, height=h, **over)
+    V = scene.vertices().reshape(-1, 3).astype(np.float64)
+    lo, hi = V.min(0), V.max(0)
+    rng = np.random.default_rng(7)
+    r = rt.Renderer(0)
+    tickets = 0
+    try:
+        for k in range(16):
+            if k % 4 == 3:  # a hair from a vertex
+                ob = V[rng.integers(0, len(V))] + rng.standard_normal(3) * 1e-4 * (hi - lo).max()
+            else:
+                ob = lo + rng.random(3) * (hi - lo)
+            fwd = rng.standard_normal(3); fwd /= np.linalg.norm(fwd)
+            right = np.cross(fwd, rng.standard_normal(3)); right /= np.linalg.norm(right)
+            up = np.cross(right, fwd)
+            sd = (hi - lo).max() * 10.0 ** rng.uniform(-3, -1)
+            hw = sd * rng.uniform(0.3, 2.0); hh = hw * h / w
+            c = ob + fwd * sd
+            cam = scene.camera
+            for q in range(3):
+                cam.ob[q] = ob[q]
+                cam.ul[q] = c[q] - right[q] * hw + up[q] * hh
+                cam.ur[q] = c[q] + right[q] * hw + up[q] * hh
+                cam.bl[q] = c[q] - right[q] * hw - up[q] * hh
+            on, con = frame(r, scene, 1)
+            off, coff = frame(r, scene, 0)
+            assert np.array_equal(on["ids"], off["ids"]), "camera %d" % k
+            assert np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32)), "camera %d" % k
+            tickets += con["view_list_tickets"]
+            print("%s camera %d: %d tickets from the lists, %d walked, %d pixels hit" % (name, k, con["view_list_tickets"], con["view_list_fallbacks"], int((on["ids"] >= 0).sum())))
+    finally:
+        r.close()
+    assert tickets > 0
+
+
+@pytest.mark.parametrize("prefix,w,h", [("scenes/temple/temple", 640, 360), ("scenes/ulica/ulica", 320, 180)])
+def test_a_ticket_the_walks_do_not_confirm_takes_the_walk(prefix, w, h):
+    """No scene here makes a ray's walk disagree with the lists' answer, so the way back to the walk is exercised by option
+    "view_list_test_fallback": every other ticket is treated as unconfirmed after its lookup and walks from its untouched
+    state.  Same frame; half of the tickets counted as walked."""
+    os.chdir(ROOT)
+    scene = rt.Scene(os.path.join(ROOT, prefix), width=w, height=h)
+    r = rt.Renderer(0)
+    try:
+        ref, cref = frame(r, scene, 0)
+        fb, cfb = frame(r, scene, 1, view_list_test_fallback=1)
+        r.set_option("view_list_test_fallback", 0)
+    finally:
+        r.close()
+    assert np.array_equal(ref["ids"], fb["ids"])
+    assert np.array_equal(ref["rgb"].view(np.uint32), fb["rgb"].view(np.uint32))
+    assert np.array_equal(ref["minmax"].view(np.uint32), fb["minmax"].view(np.uint32))
+    tiles = ((w + 7) // 8) * ((h + 7) // 8)
+    assert cfb["view_list_tickets"] + cfb["view_list_fallbacks"] == tiles
+    assert abs(cfb["view_list_fallbacks"] - tiles // 2) <= tiles // 8 + 1
