@@ -54,6 +54,7 @@ struct rtgpu_ctx {
   int opt_timing = 0;  // 0 off, 1 events around every kernel family, 2 around the two walk kernels only
   int64_t chunk_bytes = 8ll << 30;
   int waves_per_cu = 0;  // wavefronts per CU of the persistent walk kernels; 0 = what each is compiled for (its register budget)
+  int contexts_on_gpu = 1;  // option "contexts_on_gpu": a hint, how many contexts keep frames in flight on this GPU (waves_of)
   bool opt_pipeline = true;  // frame set-up on its own stream, into the set of buffers the previous frame does not use
   bool filter = true;        // staged triangle filter + batch culling (off: every listed triangle gets the exact test)
   // scene, host side
@@ -542,6 +543,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
     if (value < 8 || value > 256 || (value & (value - 1)) != 0) return fail(c, RTGPU_E_INVALID_PARAM, "light_list_texels: a power of two, 8..256");
     if (c->opt_ll_texels != (int)value) { c->opt_ll_texels = (int)value; c->ll_tried = false; c->ll.on = 0; }
   }
+  else if (!strcmp(name, "contexts_on_gpu")) { if (value < 1 || value > 16) return fail(c, RTGPU_E_INVALID_PARAM, "contexts_on_gpu: 1..16"); c->contexts_on_gpu = (int)value; }
   else if (!strcmp(name, "waves_per_cu")) { if (value < 0 || value > 64) return fail(c, RTGPU_E_INVALID_PARAM, "waves_per_cu out of range"); c->waves_per_cu = (int)value; }
   else return fail(c, RTGPU_E_INVALID_PARAM, std::string("unknown option ") + name);
   return RTGPU_OK;
@@ -1023,11 +1025,21 @@ unsigned node_blocks(size_t cap, int level) {
   return (unsigned)(level == 0 || b < 4096 ? (b ? b : 1) : 4096);
 }
 
+// Wavefronts per CU of a walk kernel compiled for `compiled` of them.  Contexts that share the GPU (frames in flight, option
+// "contexts_on_gpu") launch 12 each in scenes without secondary rays, so that the other frame's kernels and set-up find room
+// (two in flight, ms per frame with all / 12: temple 4K one rank of 8: 0.75 / 0.64, of 4: 1.29 / 0.89, of 2: 1.40 / 1.33, the
+// whole frame 1.96 / 1.95); with secondary rays a frame is many launches with host waits between them and fills the
+// gaps by itself (ulica 1080p one rank of 2: 57.1 / 58.1, of 4: 32.0 / 33.5, though of 8: 23.6 / 19.8).
+int waves_of(const rtgpu_ctx *c, int compiled) {
+  if (c->waves_per_cu) return c->waves_per_cu;
+  return c->contexts_on_gpu > 1 && c->levels == 1 && compiled > 12 ? 12 : compiled;
+}
+
 // One chunk of tiles, first half: primary rays, then nearest-hit walk and hit kernel level by level
 // (raytrace.c:170-204); with planar lights also the number of shaded hits in every node's subtree.
 int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
   const int n0 = nt_chunk * kTilePixels;
-  const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * RT_WAVES_NEAREST) + 3) / 4);
+  const int pgrid = c->num_cu * ((waves_of(c, 4 * RT_WAVES_NEAREST) + 3) / 4);
   const int64_t tx = tiles_x_of(c);
   c->prim = PrimaryP{c->cam, (int32_t)t0, nt_chunk, rank, world, (int32_t)tx, 1};
   PrimaryP queued = c->prim;
@@ -1049,7 +1061,7 @@ int chunk_trace(rtgpu_ctx *c, int64_t t0, int nt_chunk, int rank, int world) {
       fused = c->opt_fuse_hit && !(L + 1 < c->levels) && c->tex_tri[0] < 0 && c->tex_tri[1] < 0 && c->tex_tri[2] < 0 && c->tex_tri[3] < 0;
       // the primary rays' hits from the view lists where the frame has them (not the counting variant, which reports the walks)
       const bool viewed = L == 0 && c->opt_view_lists && c->vl.on && c->filter && !c->opt_count;
-      const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * (viewed ? RT_WAVES_VIEW : RT_WAVES_NEAREST)) + 3) / 4);
+      const int pgrid = c->num_cu * ((waves_of(c, 4 * (viewed ? RT_WAVES_VIEW : RT_WAVES_NEAREST)) + 3) / 4);
       const NearestArgs nargs{c->grid, c->d_rays[L], c->d_hits, c->d_ctl, L, L == 0 ? c->prim : queued,
                               c->shade, c->d_nodes, c->d_sorg, (int)c->base[L], c->vl};
 #define RT_LAUNCH_NEAREST(COUNT, RECTEST, FUSE, VL) \
@@ -1117,7 +1129,7 @@ const uint32_t *level_order(const rtgpu_ctx *c, int L) {
 int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d_ids, float *d_minmax) {
   const int n0 = nt_chunk * kTilePixels;
   const bool ends = c->opt_bundle_ends < 0 ? c->levels > 1 : c->opt_bundle_ends != 0;
-  const int pgrid = c->num_cu * (((c->waves_per_cu ? c->waves_per_cu : 4 * (ends ? RT_WAVES_ENDS : RT_WAVES)) + 3) / 4);
+  const int pgrid = c->num_cu * ((waves_of(c, 4 * (ends ? RT_WAVES_ENDS : RT_WAVES)) + 3) / 4);
   if (c->shade.nslots > 0) {
     for (int L = 0; L < c->levels; L++) {
       Span sp(c, W_SHADOW);
@@ -1156,7 +1168,7 @@ int chunk_shade(rtgpu_ctx *c, int64_t t0, int nt_chunk, float *d_rgb, int32_t *d
   KLAUNCH(c, (k_shadow<COUNT, RECTEST, ENDS>), dim3(pgrid), dim3(256), c->stream, sargs)
 #define RT_LAUNCH_SHADOW2(COUNT, RECTEST) do { if (ends) RT_LAUNCH_SHADOW(COUNT, RECTEST, true); else RT_LAUNCH_SHADOW(COUNT, RECTEST, false); } while (0)
       if (c->opt_count) { if (rectest) RT_LAUNCH_SHADOW2(true, true); else RT_LAUNCH_SHADOW2(true, false); }
-      else if (lists) KLAUNCH(c, (k_shadow<false, true, false, true>), dim3(c->waves_per_cu ? pgrid : c->num_cu * RT_WAVES_LL), dim3(256), c->stream, sargs);
+      else if (lists) KLAUNCH(c, (k_shadow<false, true, false, true>), dim3(c->num_cu * ((waves_of(c, 4 * RT_WAVES_LL) + 3) / 4)), dim3(256), c->stream, sargs);
       else { if (rectest) RT_LAUNCH_SHADOW2(false, true); else RT_LAUNCH_SHADOW2(false, false); }
 #undef RT_LAUNCH_SHADOW2
 #undef RT_LAUNCH_SHADOW

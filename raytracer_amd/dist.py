@@ -20,7 +20,6 @@ walk kernel there lasts as long as its slowest ticket while most of the machine 
 1.35 -> 1.05 ms per frame for one rank of eight, 2.10 -> 1.75 of four, 3.19 -> 2.95 of two (tools/frames_in_flight.py).
 """
 import numpy as np
-import os
 
 import torch
 import torch.distributed as dist
@@ -199,12 +198,10 @@ class FramePipeline:
         self.renderers, self.slots, self.streams = [], [], []
         for _ in range(depth):
             r = make_renderer()
-            if depth > 1 and "RTGPU_WAVES_PER_CU" not in os.environ:
-                # frames in flight share the GPU: each frame's walk kernels with 12 wavefronts a CU instead of all the CU
-                # holds, so that the other frame's kernels and set-up find room (two in flight, ms per frame with all / 12:
-                # temple 4K one rank of 8: 0.75 / 0.64, of 4: 1.29 / 0.89, of 2: 1.40 / 1.33, the whole frame 1.96 / 1.95;
-                # ulica 1080p one rank of 8: 23.6 / 19.8)
-                r.set_option("waves_per_cu", 12)
+            if depth > 1:
+                # frames in flight share the GPU: the library then sizes the walk kernels of scenes without secondary rays so
+                # that the other frame's kernels and set-up find room beside them (rtgpu.hip: waves_of)
+                r.set_option("contexts_on_gpu", depth)
             dev = torch.device("cuda", r.device)
             s = torch.cuda.current_stream(dev) if depth == 1 else torch.cuda.Stream(dev)
             with torch.cuda.stream(s):

@@ -290,9 +290,9 @@ RT_Bitmap *rtHostRenderDevices(RT_Scene *scene, RT_Camera *camera, int ndev, int
       GPUOK(NULL, rtgpu_create(devs[r], &q->ctx));
       HIPOK(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
       GPUOK(q->ctx, rtgpu_set_stream(q->ctx, q->stream));
-      /* two frames in flight share the device: their walk kernels with 12 wavefronts a CU each instead of all it holds
-       * (one rank's share of eight, temple 4K 0.75 -> 0.64 ms, ulica 1080p 23.6 -> 19.8 ms per frame) */
-      if (depth > 1 && !getenv("RTGPU_WAVES_PER_CU")) GPUOK(q->ctx, rtgpu_set_option(q->ctx, "waves_per_cu", 12));
+      /* frames in flight share the device: the library sizes the walk kernels of scenes without secondary rays so that
+       * the other frame's find room (one rank's share of eight, temple 4K, two in flight: 0.75 -> 0.64 ms per frame) */
+      if (depth > 1) GPUOK(q->ctx, rtgpu_set_option(q->ctx, "contexts_on_gpu", depth));
       GPUOK(q->ctx, rtgpu_scene_upload(q->ctx, &flat->desc));
       HIPOK(hipMalloc((void **)&q->rgb, sizeof(float) * 3 * (size_t)(q->npix + 1)));
       HIPOK(hipMalloc((void **)&q->ids, sizeof(int32_t) * (size_t)(q->npix + 1)));
