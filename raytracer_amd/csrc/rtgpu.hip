@@ -172,7 +172,7 @@ struct rtgpu_ctx {
   uint32_t *d_vl_offsets = nullptr, *d_vl_pieces = nullptr, *d_vl_cursor = nullptr, *d_vl_totals = nullptr;
   int32_t *d_vl_refs = nullptr, *d_vl_piece_tri = nullptr;
   ViewRectD *d_vl_rects = nullptr;
-  size_t cap_vl_texels = 0, cap_vl_refs = 0, cap_vl_nt = 0;
+  size_t cap_vl_texels = 0, cap_vl_refs = 0, cap_vl_tris = 0, cap_vl_cursor = 0;  // (triangles the rectangles', pieces' and piece map's buffers are for; entries of the cursors)
   bool vl_no_memory = false;  // an allocation for them failed once: this context goes without
   int opt_ll_kernel = 1;  // option "light_list_kernel": the lists' own kernel where it applies: 0 never (inside k_shadow only), 1 where a wavefront gets many tickets, 2 always
   // timing
@@ -789,6 +789,7 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
   if ((uint64_t)c->nt * ((ntexels + 63) / 64 + 1) >= (1ull << 32)) return RTGPU_OK;
   const size_t want_refs = std::max<size_t>((size_t)1 << 20, 64 * ntexels + 16 * (size_t)c->nt);
   const int nscan_t = (int)((ntexels + 1 + kScanTile - 1) / kScanTile), nscan_p = (int)(((size_t)c->nt + 1 + kScanTile - 1) / kScanTile);
+  const size_t want_cursor = std::max(ntexels, (size_t)c->nt) + 2;  // (the cursors of the two scans: pieces per triangle, references per texel)
   auto grow = [&]() -> int {
     int rc;
     if (ntexels + 2 > c->cap_vl_texels) {
@@ -800,22 +801,26 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
       c->cap_vl_refs = 0;
       if ((rc = dev_alloc(c, &c->d_vl_refs, want_refs)) || (rc = dev_alloc(c, &c->alt.d_vl_refs, want_refs))) return rc;
       c->cap_vl_refs = want_refs;
-      c->cap_vl_nt = 0;  // (the pieces' buffer goes with the references')
+      c->cap_vl_tris = 0;  // (the piece map's size goes with the references')
     }
-    const size_t want_nt = std::max(ntexels, (size_t)c->nt) + 2;
-    if (want_nt > c->cap_vl_nt) {
-      c->cap_vl_nt = 0;
+    if ((size_t)c->nt > c->cap_vl_tris) {
+      c->cap_vl_tris = 0;
+      const size_t pieces = c->cap_vl_refs / 64 + (size_t)c->nt + 1;
       if ((rc = dev_alloc(c, &c->d_vl_rects, (size_t)c->nt)) || (rc = dev_alloc(c, &c->d_vl_pieces, (size_t)c->nt + 2)) ||
-          (rc = dev_alloc(c, &c->d_vl_piece_tri, c->cap_vl_refs / 64 + (size_t)c->nt + 1)) ||
-          (hipMemset(c->d_vl_piece_tri, 0, sizeof(int32_t) * (c->cap_vl_refs / 64 + (size_t)c->nt + 1)) != hipSuccess ? (rc = RTGPU_E_MEMORY) : 0) ||
-          (rc = dev_alloc(c, &c->d_vl_cursor, want_nt)) || (rc = dev_alloc(c, &c->d_vl_totals, want_nt / kScanTile + 2)))
+          (rc = dev_alloc(c, &c->d_vl_piece_tri, pieces)) ||
+          (hipMemset(c->d_vl_piece_tri, 0, sizeof(int32_t) * pieces) != hipSuccess ? (rc = RTGPU_E_MEMORY) : 0))
         return rc;
-      c->cap_vl_nt = want_nt;
+      c->cap_vl_tris = (size_t)c->nt;
+    }
+    if (want_cursor > c->cap_vl_cursor) {
+      c->cap_vl_cursor = 0;
+      if ((rc = dev_alloc(c, &c->d_vl_cursor, want_cursor)) || (rc = dev_alloc(c, &c->d_vl_totals, want_cursor / kScanTile + 2))) return rc;
+      c->cap_vl_cursor = want_cursor;
     }
     return RTGPU_OK;
   };
   // (a buffer about to be replaced may still be read by the previous frame's kernels)
-  if (ntexels + 2 > c->cap_vl_texels || want_refs > c->cap_vl_refs || std::max(ntexels, (size_t)c->nt) + 2 > c->cap_vl_nt || !c->d_vl_piece_tri) {
+  if (ntexels + 2 > c->cap_vl_texels || want_refs > c->cap_vl_refs || (size_t)c->nt > c->cap_vl_tris || want_cursor > c->cap_vl_cursor) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(bs));
     const int rc = grow();
@@ -823,7 +828,7 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
       (void)hipGetLastError();
       dev_free(&c->d_vl_offsets); dev_free(&c->alt.d_vl_offsets); dev_free(&c->d_vl_refs); dev_free(&c->alt.d_vl_refs);
       dev_free(&c->d_vl_rects); dev_free(&c->d_vl_pieces); dev_free(&c->d_vl_cursor); dev_free(&c->d_vl_totals); dev_free(&c->d_vl_piece_tri);
-      c->cap_vl_texels = c->cap_vl_refs = c->cap_vl_nt = 0;
+      c->cap_vl_texels = c->cap_vl_refs = c->cap_vl_tris = c->cap_vl_cursor = 0;
       c->vl_no_memory = true;
       return RTGPU_OK;
     }
@@ -837,7 +842,7 @@ int build_view_lists(rtgpu_ctx *c, hipStream_t bs) {
   KLAUNCH(c, k_ll_starts, dim3((unsigned)((nt + 2 + 255) / 256)), dim3(256), bs, c->d_vl_pieces, (const uint32_t *)c->d_vl_totals, nt + 1, 0u, c->d_vl_cursor);
   HIPCHK(c, hipMemsetAsync(c->d_vl_offsets, 0, sizeof(uint32_t) * (ntexels + 2), bs));
   // (every triangle's pieces: at most a 64th of its references, and one)
-  const uint32_t cap_pieces = (uint32_t)std::min<size_t>(c->cap_vl_refs / 64 + (size_t)nt + 1, 0xffffffffu);
+  const uint32_t cap_pieces = (uint32_t)std::min<size_t>(c->cap_vl_refs / 64 + c->cap_vl_tris + 1, 0xffffffffu);  // (what the piece map was allocated for)
   KLAUNCH(c, k_view_pieces, dim3((unsigned)((nt + 255) / 256)), dim3(256), bs, nt, (const uint32_t *)c->d_vl_pieces, cap_pieces, c->d_vl_piece_tri);
   const int sblocks = 32 * c->num_cu;
   KLAUNCH(c, k_view_scatter<false>, dim3(sblocks), dim3(256), bs, (const ViewRectD *)c->d_vl_rects, (const uint32_t *)c->d_vl_pieces, (const int32_t *)c->d_vl_piece_tri,

@@ -213,3 +213,24 @@ def test_a_ticket_the_walks_do_not_confirm_takes_the_walk(prefix, w, h):
     tiles = ((w + 7) // 8) * ((h + 7) // 8)
     assert cfb["view_list_tickets"] + cfb["view_list_fallbacks"] == tiles
     assert abs(cfb["view_list_fallbacks"] - tiles // 2) <= tiles // 8 + 1
+
+
+def test_one_context_through_scenes_of_growing_and_shrinking_size():
+    """The lists' buffers are kept from frame to frame and grown by what needs more room (texels, references, triangles):
+    a small scene at a large resolution, then a scene of many more triangles at the same resolution, a lower one, the small
+    scene again: the frame with the lists is the frame from the walks every time."""
+    os.chdir(ROOT)
+    r = rt.Renderer(0)
+    try:
+        for prefix, over, w, h in [("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 1600, 900), ("scenes/s3/s3", {}, 1600, 900),
+                                    ("scenes/temple/temple", {}, 1600, 900), ("scenes/temple/temple", {}, 200, 120),
+                                    ("scenes/ulica/ulica", {}, 320, 180), ("scenes/test/s2", {"atr": "scenes/temple/temple.atr"}, 2000, 1100)]:
+            over = {k: os.path.join(ROOT, v) for k, v in over.items()}
+            scene = rt.Scene(os.path.join(ROOT, prefix), width=w, height=h, **over)
+            on, con = frame(r, scene, 1)
+            off, coff = frame(r, scene, 0)
+            assert np.array_equal(on["ids"], off["ids"]), prefix
+            assert np.array_equal(on["rgb"].view(np.uint32), off["rgb"].view(np.uint32)), prefix
+            assert con["view_list_tickets"] > 0 and coff["view_list_tickets"] == 0
+    finally:
+        r.close()
