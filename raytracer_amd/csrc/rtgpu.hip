@@ -156,6 +156,11 @@ struct rtgpu_ctx {
   int opt_ll_levels = 4;        // option "light_list_levels": 1..4 levels of texels, each twice as coarse as the one before
   int opt_ll_texels = 256;      // option "light_list_texels": texels per face edge of the finest level (a power of two, 8..256)
   bool ll_tried = false;        // the uploaded scene's lists were built, or found not to apply
+  // option "light_lists_after" (its default from the environment, RTGPU_LIGHT_LISTS_AFTER, else 1): frames of an uploaded
+  // scene that are set up before its lists are built.  The rectangles are worked out on the host (temple: 0.14 s), which a
+  // caller that renders one frame of a scene, like the reference's command line, would pay for nothing
+  int opt_ll_after = 1;
+  int frames_of_scene = 0;      // rtgpu_frame_begin calls since the scene was uploaded
   bool all_opaque = false;      // no triangle of the scene is transparent
   LightListsP ll = {};
   uint32_t *d_ll_offsets = nullptr;
@@ -430,6 +435,7 @@ int rtgpu_create(int device, rtgpu_ctx **out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RTGPU_E_NO_DEVICE;
   rtgpu_ctx *c = new rtgpu_ctx();
   c->device = device;
+  if (const char *e = getenv("RTGPU_LIGHT_LISTS_AFTER")) { const long v = strtol(e, nullptr, 10); if (v >= 0 && v <= 1000000) c->opt_ll_after = (int)v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return RTGPU_E_NO_DEVICE;
@@ -530,6 +536,7 @@ int rtgpu_set_option(rtgpu_ctx *c, const char *name, int64_t value) {
   else if (!strcmp(name, "queue_sizing")) { c->adaptive_queues = value != 0; c->have_ratio = false; }
   else if (!strcmp(name, "pipeline")) c->opt_pipeline = value != 0;
   else if (!strcmp(name, "light_lists")) c->opt_light_lists = value != 0;
+  else if (!strcmp(name, "light_lists_after")) { if (value < 0 || value > 1000000) return fail(c, RTGPU_E_INVALID_PARAM, "light_lists_after: 0 .. 1000000 frames"); c->opt_ll_after = (int)value; }
   else if (!strcmp(name, "view_lists")) c->opt_view_lists = value != 0;
   else if (!strcmp(name, "view_list_test_fallback")) c->opt_vl_test_fallback = value != 0;
   else if (!strcmp(name, "view_list_capacity")) { if (value < 0 || value > (1ll << 30)) return fail(c, RTGPU_E_INVALID_PARAM, "view_list_capacity: 0 (planned) .. 2^30"); c->opt_vl_capacity = value; }
@@ -633,6 +640,7 @@ int rtgpu_scene_upload(rtgpu_ctx *c, const rtgpu_scene_desc *s) {
   c->all_opaque = transparent == 0;
   c->ll_tried = false;
   c->ll.on = 0;
+  c->frames_of_scene = 0;
   c->chunk_tiles_cap = 0;
   c->have_ratio = false;
   for (int L = 0; L < kMaxLevels; L++) c->ratio[L] = L == 0 ? 1.0 : 0.0;
@@ -991,7 +999,8 @@ int rtgpu_frame_begin(rtgpu_ctx *c, const rtgpu_camera *cam) {
   sp.total_flux = total_flux; sp.distmod = c->distmod;
   if (sp.nslots != c->shade.nslots) c->chunk_tiles_cap = 0;
   c->shade = sp;
-  if (c->opt_light_lists && (rc = ensure_light_lists(c))) return rc;
+  if (c->opt_light_lists && c->frames_of_scene >= c->opt_ll_after && (rc = ensure_light_lists(c))) return rc;
+  if (c->frames_of_scene < (1 << 30)) c->frames_of_scene++;
   c->have_frame = true;
   return RTGPU_OK;
 }

@@ -198,6 +198,7 @@ class FramePipeline:
         self.renderers, self.slots, self.streams = [], [], []
         for _ in range(depth):
             r = make_renderer()
+            r.set_option("light_lists_after", 0)  # (a sequence of frames: the scene's light lists from its first frame on)
             if depth > 1:
                 # frames in flight share the GPU: the library then sizes the walk kernels of scenes without secondary rays so
                 # that the other frame's kernels and set-up find room beside them (rtgpu.hip: waves_of)

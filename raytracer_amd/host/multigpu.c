@@ -293,6 +293,7 @@ RT_Bitmap *rtHostRenderDevices(RT_Scene *scene, RT_Camera *camera, int ndev, int
       /* frames in flight share the device: the library sizes the walk kernels of scenes without secondary rays so that
        * the other frame's find room (one rank's share of eight, temple 4K, two in flight: 0.75 -> 0.64 ms per frame) */
       if (depth > 1) GPUOK(q->ctx, rtgpu_set_option(q->ctx, "contexts_on_gpu", depth));
+      if (frames > 1) GPUOK(q->ctx, rtgpu_set_option(q->ctx, "light_lists_after", 0)); /* a sequence of frames: the lists from the first on */
       GPUOK(q->ctx, rtgpu_scene_upload(q->ctx, &flat->desc));
       HIPOK(hipMalloc((void **)&q->rgb, sizeof(float) * 3 * (size_t)(q->npix + 1)));
       HIPOK(hipMalloc((void **)&q->ids, sizeof(int32_t) * (size_t)(q->npix + 1)));

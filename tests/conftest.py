@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# The light lists of a scene are built from its second frame on (a caller that renders one frame does not pay for them);
+# the tests render one frame of most scenes and want that frame answered from the lists: from the first frame on.
+os.environ.setdefault("RTGPU_LIGHT_LISTS_AFTER", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

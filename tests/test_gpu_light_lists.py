@@ -120,3 +120,27 @@ def test_the_lists_own_kernel_and_the_lists_inside_the_walk_kernel_agree(w, h):
     assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
     assert ca["shadow_list_tickets"] == cb["shadow_list_tickets"] > 0
     assert ca["shadow_list_fallbacks"] == cb["shadow_list_fallbacks"]
+
+
+def test_the_lists_are_built_from_the_second_frame_of_a_scene_on():
+    """Option "light_lists_after" (default 1; the tests run with 0 from the environment): the first frame of an uploaded scene
+    walks (a caller that renders one frame does not wait for the rectangles to be worked out on the host), the second
+    builds the lists; an upload of the same scene again changes nothing, another scene starts over.  Same frames."""
+    os.chdir(ROOT)
+    scene = rt.Scene(os.path.join(ROOT, "scenes/temple/temple"), width=480, height=270)
+    other = rt.Scene(os.path.join(ROOT, "scenes/test/s2"), width=480, height=270, atr=os.path.join(ROOT, "scenes/temple/temple.atr"))
+    r = rt.Renderer(0)
+    try:
+        r.set_option("light_lists_after", 1)
+        first, c1 = frame(r, scene, 1)
+        second, c2 = frame(r, scene, 1)  # (uploads the same scene again)
+        third, c3 = frame(r, scene, 1)
+        o1, d1 = frame(r, other, 1)
+        o2, d2 = frame(r, other, 1)
+    finally:
+        r.close()
+    assert c1["shadow_list_tickets"] == 0 and c2["shadow_list_tickets"] > 0 and c3["shadow_list_tickets"] == c2["shadow_list_tickets"]
+    assert d1["shadow_list_tickets"] + d1["shadow_list_fallbacks"] == 0 and d2["shadow_list_tickets"] + d2["shadow_list_fallbacks"] > 0
+    for a, b in ((first, second), (first, third), (o1, o2)):
+        assert np.array_equal(a["ids"], b["ids"])
+        assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))

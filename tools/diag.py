@@ -8,6 +8,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# (the measuring tools, which import this module for its scene table, want a scene's light lists from its first frame on)
+os.environ.setdefault("RTGPU_LIGHT_LISTS_AFTER", "0")
 import raytracer_amd as rt  # noqa: E402
 
 SCENES = {"temple": "scenes/temple/temple", "ulica": "scenes/ulica/ulica", "s3": "scenes/s3/s3", "s5": "scenes/s5/s5",
