@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(256) k_view_scatter(const ViewRectD *__restric
 //     |X(axis)| - 1.001 rho |gradient| > 1.00001 (|det(axis)| + rho |N|) + 2 kc_max.
 // In front: d = dp / det with dp = i.N - o.N the same for all rays; as in fan_plane_behind no ray is accepted if
 // |det(axis)| - rho |N| > 1.5 kc_max (one sign, large enough) and sign(det) dp < -2 |ik| kc_max.  A NaN compares false: passes.
+// tests/test_filter_cpu.py restates it in binary32 and checks that no accepted triangle is dropped.
 RT_D bool apex_slabs_pass(const RecA &A, f3 ab, f3 P, float an, float kc_max, f3 o, f3 axis, float rho) {
   const f3 w1 = mk3(__builtin_fmaf(A.ac.y, o.z, __builtin_fmaf(-A.ac.z, o.y, -A.q.x)), __builtin_fmaf(A.ac.z, o.x, __builtin_fmaf(-A.ac.x, o.z, -A.q.y)),
                     __builtin_fmaf(A.ac.x, o.y, __builtin_fmaf(-A.ac.y, o.x, -A.q.z)));

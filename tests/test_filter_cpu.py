@@ -598,3 +598,62 @@ def test_plane_behind_the_fan_never_drops_a_hit(scale, offset, box):
         ro2 = (light2 - other).astype(np.float64)
         smax2 = (np.sqrt(np.maximum((ro2 * ro2).sum(1), ((light2 - o).astype(np.float64) ** 2).sum(1))).astype(F) * F(1.00001)).astype(F)
         assert fan_plane_behind(T, kc_max, lo, hi, light2, smax2).mean() > 0.5
+
+
+def apex_slabs_pass(T, kc_max, o, axis, rho):
+    """apex_slabs_pass of rt_view_kernels.h, operation by operation in float32: may any ray that starts at o with a direction
+    within rho of `axis` pass the record's three slabs with a hit in front of o?"""
+    N, ac, Q, ab, P, an = T["N"], T["ac"], T["Q"], T["ab"], T["P"], T["an"]
+    with np.errstate(all="ignore"):
+        w1 = np.stack([fma(ac[:, 1], o[:, 2], fma(-ac[:, 2], o[:, 1], -Q[:, 0])), fma(ac[:, 2], o[:, 0], fma(-ac[:, 0], o[:, 2], -Q[:, 1])),
+                       fma(ac[:, 0], o[:, 1], fma(-ac[:, 1], o[:, 0], -Q[:, 2]))], 1)
+        w2 = np.stack([fma(ab[:, 1], o[:, 2], fma(-ab[:, 2], o[:, 1], P[:, 0])), fma(ab[:, 2], o[:, 0], fma(-ab[:, 0], o[:, 2], P[:, 1])),
+                       fma(ab[:, 0], o[:, 1], fma(-ab[:, 1], o[:, 0], P[:, 2]))], 1)
+        two = np.full_like(w1, F(2))
+        g1 = fma(two, w1, -N)
+        g2 = fma(-two, w2, -N)
+        g3 = fma(-two, w2, g1)
+        along = lambda v: fma(axis[:, 0], v[:, 0], fma(axis[:, 1], v[:, 1], axis[:, 2] * v[:, 2]))
+        norm = lambda v: (np.sqrt(fma(v[:, 0], v[:, 0], fma(v[:, 1], v[:, 1], v[:, 2] * v[:, 2]))).astype(F) * F(1.001)).astype(F)
+        det = along(N)
+        rn = (rho * norm(N)).astype(F)
+        Tt = fma(np.abs(det) + rn, np.full_like(det, F(1.00001)), kc_max + kc_max)
+        out = ((np.abs(along(g1)) - rho * norm(g1) > Tt) | (np.abs(along(g2)) - rho * norm(g2) > Tt) | (np.abs(along(g3)) - rho * norm(g3) > Tt))
+        dp = fma(-o[:, 0], N[:, 0], fma(-o[:, 1], N[:, 1], fma(-o[:, 2], N[:, 2], an)))
+        sdp = np.where(det < 0, -dp, dp)
+        behind = (np.abs(det) - rn > F(1.5) * kc_max) & (sdp < F(-2.0) * norm(ac) * kc_max)
+    return ~(out | behind)
+
+
+@pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (0.05, 20.0), (10.0, -200.0), (1.0, 3000.0)])
+@pytest.mark.parametrize("cone", ["ray", "tile", "wide"])
+def test_rays_from_one_point_in_a_cone(scale, offset, cone):
+    """The record-level test for the primary rays of one tile (apex_slabs_pass): whatever cone around an axis holds the ray
+    (the ray alone, a cone as narrow as a tile of pixels, a wide one), a triangle the exact test accepts for the ray is
+    never dropped; and triangles elsewhere are dropped.  Rays aimed at edges and vertices, observers near and far,
+    coordinates far from the origin."""
+    rng = np.random.default_rng(int(scale * 1000) + int(offset) + 7 * len(cone))
+    n = 300000
+    a, ab, ac, o, r = make_cases(rng, n, scale, offset, aim_edges)
+    acc = exact_test(a, ab, ac, o, r)[0]
+    assert acc.mean() > 0.05
+    spread = {"ray": 0.0, "tile": 10.0 ** rng.uniform(-4, -2, (n, 1)), "wide": 10.0 ** rng.uniform(-1.5, 0, (n, 1))}[cone]
+    ax = r.astype(np.float64) + rng.standard_normal((n, 3)) * spread
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    axis = ax.astype(F)
+    dr = (r - axis).astype(F)
+    with np.errstate(all="ignore"):
+        rho = fma(np.sqrt(dr[:, 0] * dr[:, 0] + dr[:, 1] * dr[:, 1] + dr[:, 2] * dr[:, 2]).astype(F), np.full(n, F(1.001)), np.full(n, F(1e-7)))
+    rho = (rho * rng.uniform(1.0, 2.0, n).astype(F)).astype(F)  # (the cone of a tile is as wide as its widest ray)
+    T = preprocess(a, ab, ac)
+    _, onorm, _ = ray_side(o, r)
+    kc_max = fma(T["k1"], onorm, np.abs(T["k2"]))
+    keep = apex_slabs_pass(T, kc_max, o, axis, rho)
+    assert keep[acc].all(), "the cone's record-level test dropped a triangle a ray of the cone hits"
+    if cone in ("ray", "tile") and offset == 0.0:
+        a2, ab2, ac2 = np.roll(a, 1, 0), np.roll(ab, 1, 0), np.roll(ac, 1, 0)
+        T2 = preprocess(a2, ab2, ac2)
+        acc2 = exact_test(a2, ab2, ac2, o, r)[0]
+        keep2 = apex_slabs_pass(T2, fma(T2["k1"], onorm, np.abs(T2["k2"])), o, axis, rho)
+        assert keep2[acc2].all()
+        assert (~keep2).mean() > 0.3
