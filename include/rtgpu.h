@@ -166,7 +166,25 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * "fuse_hit" (default 1: a recursion level that neither spawns rays nor meets a textured triangle shades its hits at the end
  * of the nearest-hit walk, so that the hit records do not go through memory; 0: always in a kernel of its own; same image),
  * "filter" (default 1; 0 switches off the conservative triangle filter and the batch culling of the
- * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation). */
+ * walk kernels, so that every listed triangle gets the exact test: same image, slower; for validation),
+ * "light_lists" (default 1: in a scene without a transparent triangle, with point lights and at most 2^20 pairs of a triangle
+ * and a light, the shadow queries towards each point light are answered
+ * from lists over the directions from that light, built once per scene on the host, where the lists can tell; the others take
+ * the walk; 0: every shadow query walks; same image), "light_lists_after" (default 1: the lists are built when the scene is
+ * rendered a second time, so that a scene rendered once does not pay for them; 0: with the first frame; N: with frame N + 1),
+ * "light_list_levels" (default 4: 1..4 levels of texels, each twice as coarse as the one before), "light_list_texels"
+ * (default 256: texels per face edge of the finest level, a power of two from 8 to 256), "light_list_kernel" (default 1: the
+ * lists get a kernel of their own where a launch gives every wavefront many tiles; 0: never, they are read inside the shadow
+ * walk's kernel; 2: wherever that kernel applies),
+ * "view_lists" (default 1: with the triangle filter on and "count" off, the nearest-hit queries of the primary rays are answered
+ * from lists over the screen, built with every frame's set-up on the device, each answer checked against the ray's own walk
+ * through the grid up to the hit; 0: every primary ray walks; same image), "view_list_texel_shift" (default 1: a texel of those
+ * lists is 8 << shift pixels wide and high; 0..4), "view_list_capacity" (default 0: the references of those lists get
+ * max(2^20, 64 per texel + 16 per triangle) places; otherwise that many, up to 2^30; a frame whose lists need more takes the
+ * walk), "view_list_test_fallback" (default 0; 1 makes every other tile reject its list's answer and walk: for tests),
+ * "contexts_on_gpu" (default 1: how many contexts render on this GPU at the same time, 1..16; with more than one a scene with a
+ * plain grid gets 12 wavefronts per CU in its walk kernels instead of what they are compiled for, so that the frames share the
+ * GPU's compute units instead of queueing for them; same image). */
 int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);
 
 /* Copies the scene to the GPU (replaces RT_Scene as the renderer's input).  A scene equal in every array and parameter to
