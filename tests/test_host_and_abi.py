@@ -25,6 +25,19 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
+def test_header_describes_every_option_the_library_accepts():
+    src = open(os.path.join(ROOT, "raytracer_amd", "csrc", "rtgpu.hip")).read()
+    body = src[src.index("int rtgpu_set_option("):]
+    body = body[:body.index("unknown option")]
+    options = sorted(set(re.findall(r'strcmp\(name, "([a-z_]+)"\)', body)))
+    assert len(options) >= 20
+    text = open(os.path.join(ROOT, "include", "rtgpu.h")).read()
+    comment = text[:text.index("int rtgpu_set_option(")]
+    comment = comment[comment.rindex("/*"):]
+    for o in options:
+        assert '"%s"' % o in comment, o
+
+
 def test_host_layer_exports_reference_entry_points():
     lib = rt.host_lib()
     for n in ["rtSceneLoad", "rtSceneConfigureRenderer", "rtSceneSetSurfaces", "rtSceneSetLights", "rtSceneSetPlanarLights",
