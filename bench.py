@@ -9,9 +9,10 @@ rtVisualizedSceneToBitmap do: per-triangle preprocess, grid build, primary rays,
 shading with one shadow query per (hit, light), global min/max, tone map to RGBA8, and with N>1 the
 min/max all-reduce and the RGBA8 tile gather to rank 0 (RCCL).  The scene is uploaded to HBM before
 the timed region; the finished image stays in HBM on rank 0.  The frame is split by 8x8 tiles over
-the ranks, so total work is fixed as N grows ("strong" scaling).  Two frames are in flight on every GPU
-(raytracer_amd.dist.FramePipeline: each in its own context and stream; a frame's exchange and the latency-bound end of
-its walk kernels run under the other frame's kernels); all K frames are complete when the timed region ends, and
+the ranks, so total work is fixed as N grows ("strong" scaling).  Two frames are in flight on every GPU, three from
+eight GPUs on (raytracer_amd.dist.FramePipeline, headline_depth: each in its own context and stream; a frame's exchange
+and the latency-bound end of its walk kernels run under the other frames' kernels; the process starts HIP with a hardware
+queue for every stream, GPU_MAX_HW_QUEUES=16); all K frames are complete when the timed region ends, and
 ms_per_step is the region's length / K.  On one GPU the line also carries one_frame_at_a_time: the same workload with one
 frame in flight, where a kernel's launch time is its own (value, ms_per_step, kernel times and roofline of that run).
 config.frames_in_flight says how many, --frames-in-flight overrides; frame_latency_ms is one frame alone, start to
@@ -53,6 +54,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+HW_QUEUES = 16  # hardware queues HIP may share among this process's streams (GPU_MAX_HW_QUEUES; main() says why)
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # HBM3E peak, GB/s
@@ -299,7 +301,7 @@ def run_leg(env, scene_name, width, height, steps, warmup, depth, latency_reps=3
                                                         " + RCCL min/max all-reduce + RGBA8 tile gather" if world > 1 else ""),
                    "rays_per_frame": int(rays_frame), "rays_per_pixel": round(rays_frame / (width * height), 2),
                    "tiling": "8x8 tiles round-robin over %d rank(s)" % world,
-                   "frames_in_flight": depth, "chunks_per_frame_rank0": chunks["chunks"], "chunks_rerendered_rank0": chunks["chunks_rerendered"]},
+                   "frames_in_flight": depth, "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES") or 4), "chunks_per_frame_rank0": chunks["chunks"], "chunks_rerendered_rank0": chunks["chunks_rerendered"]},
         "kernel_ms_per_frame_rank0": dict({k: round(v / max(warm_frames, 1), 3) for k, v in tim_warm.items() if k.endswith("_ms") and k not in ("preprocess_ms", "grid_ms")},
                                           **{k: round(tim[k] / timed_frames, 3) for k in ("nearest_ms", "shadow_ms")}),
         "setup_ms_on_build_stream_rank0": {k: round(tim_warm[k] / max(warm_frames, 1), 3) for k in ("preprocess_ms", "grid_ms")},
@@ -323,7 +325,7 @@ def main():
     ap.add_argument("--scene", default="temple")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = 2 for the headline workload, and for the config5 legs 1 on one GPU, 2 on several")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="0 = for the headline workload 2 (3 from 8 GPUs on), and for the config5 legs 1 on one GPU, 2 on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-width", type=int, default=960)
     ap.add_argument("--cpu-height", type=int, default=540)
@@ -343,10 +345,20 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # HIP maps a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, four by default; a new stream goes to the
+    # queue with the fewest), and two streams on one queue run one after the other.  Two frames in flight keep four streams
+    # busy (each context's and the one its next frame is set up on) beside the contexts' own streams, torch's default
+    # stream and RCCL's: which of them share a queue depends on the order they were made in (temple 4K on one GPU, two
+    # frames in flight: 1.96 ms per frame with four queues, 1.83 with eight, 1.80 with sixteen, 2.59 with two; the same
+    # with the collectives of a group of one: 1.82 / 2.33 / 1.82).  Sixteen: a queue for every stream of the process.
+    # Read when the HIP runtime starts, so set before torch is imported.
+    if int(os.environ.get("GPU_MAX_HW_QUEUES") or 0) < HW_QUEUES:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES)
+
     import torch
     import torch.distributed as dist
     import raytracer_amd as rt
-    from raytracer_amd.dist import default_depth
+    from raytracer_amd.dist import default_depth, headline_depth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -367,10 +379,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     env = {"torch": torch, "dist": dist, "rt": rt, "dev": dev, "rank": rank, "world": world, "local_rank": local_rank}
-    # Frames in flight on this rank's GPU (FramePipeline): two for the headline workload whatever N (the latency-bound end of a
-    # frame's walk kernels runs under the next frame's; the same setting for every N, so that the values compare), and what
+    # Frames in flight on this rank's GPU (FramePipeline): what dist.headline_depth says for the headline workload (two; three
+    # from eight GPUs on: the latency-bound end of a frame's walk kernels runs under the next frames'), and what
     # dist.default_depth says for the config5 legs (one on a single GPU: ulica's frames fill it by themselves)
-    depth = args.frames_in_flight if args.frames_in_flight > 0 else 2
+    depth = args.frames_in_flight if args.frames_in_flight > 0 else headline_depth(world)
     leg_depth = args.frames_in_flight if args.frames_in_flight > 0 else default_depth(world)
     main_leg = run_leg(env, args.scene, args.width, args.height, args.steps, args.warmup, depth)
     # ... and the same workload one frame at a time on a single GPU: a kernel's launch time is then its own (the counter

@@ -183,8 +183,10 @@ int rtgpu_set_null_stream(rtgpu_ctx *ctx);
  * max(2^20, 64 per texel + 16 per triangle) places; otherwise that many, up to 2^30; a frame whose lists need more takes the
  * walk), "view_list_test_fallback" (default 0; 1 makes every other tile reject its list's answer and walk: for tests),
  * "contexts_on_gpu" (default 1: how many contexts render on this GPU at the same time, 1..16; with more than one a scene with a
- * plain grid gets 12 wavefronts per CU in its walk kernels instead of what they are compiled for, so that the frames share the
- * GPU's compute units instead of queueing for them; same image). */
+ * plain grid gets 12 wavefronts per CU in its walk kernels (8 with three contexts or more) instead of what they are compiled
+ * for, so that the frames share the GPU's compute units instead of queueing for them; same image.  Every context keeps two
+ * streams busy, its caller's and one of its own for the next frame's set-up: a process with several should start HIP with
+ * as many hardware queues, GPU_MAX_HW_QUEUES=16 in its environment, or streams that share a queue take turns). */
 int rtgpu_set_option(rtgpu_ctx *ctx, const char *name, int64_t value);
 
 /* Copies the scene to the GPU (replaces RT_Scene as the renderer's input).  A scene equal in every array and parameter to

@@ -1043,10 +1043,13 @@ unsigned node_blocks(size_t cap, int level) {
 // "contexts_on_gpu") launch 12 each in scenes without secondary rays, so that the other frame's kernels and set-up find room
 // (two in flight, ms per frame with all / 12: temple 4K one rank of 8: 0.75 / 0.64, of 4: 1.29 / 0.89, of 2: 1.40 / 1.33, the
 // whole frame 1.96 / 1.95); with secondary rays a frame is many launches with host waits between them and fills the
-// gaps by itself (ulica 1080p one rank of 2: 57.1 / 58.1, of 4: 32.0 / 33.5, though of 8: 23.6 / 19.8).
+// gaps by itself (ulica 1080p one rank of 2: 57.1 / 58.1, of 4: 32.0 / 33.5, though of 8: 23.6 / 19.8).  Three contexts or
+// more launch 8 each (with a hardware queue for every stream, GPU_MAX_HW_QUEUES=16; one rank of 8, ms per frame with 8 / 12
+// wavefronts a CU: two in flight 0.57 / 0.60, three 0.47 / 0.52; one rank of 4: two 0.81 / 0.72, three 0.77 / 0.77).
 int waves_of(const rtgpu_ctx *c, int compiled) {
   if (c->waves_per_cu) return c->waves_per_cu;
-  return c->contexts_on_gpu > 1 && c->levels == 1 && compiled > 12 ? 12 : compiled;
+  const int shared = c->contexts_on_gpu >= 3 ? 8 : 12;  // (two contexts: 12 a CU each; three or more: 8)
+  return c->contexts_on_gpu > 1 && c->levels == 1 && compiled > shared ? shared : compiled;
 }
 
 // One chunk of tiles, first half: primary rays, then nearest-hit walk and hit kernel level by level

@@ -174,12 +174,19 @@ class FrameRenderer:
 
 
 def default_depth(world):
-    """Frames in flight on `world` GPUs.  A share of a frame leaves most of the machine idle for most of a walk kernel:
-    two in flight (one rank of eight 1.35 -> 1.05 ms per frame; three: 1.14).  A whole 4K frame fills one GPU except at
-    the ends of its two walk kernels; three frames in flight put other frames' kernels there (5.55 -> 5.45 ms per frame;
-    two: 5.55, the two frames fall into step; four: 5.50), but a kernel's launch time then depends on what runs beside
-    it, so one GPU renders one frame at a time unless asked otherwise."""
+    """Frames in flight on each of `world` GPUs for a workload of many launches per frame (secondary rays; bench.py's
+    config5 legs).  A share of a frame leaves most of the machine idle for most of a walk kernel: two in flight (one rank
+    of eight 1.35 -> 1.05 ms per frame; three: 1.14).  A whole frame of that kind fills one GPU by itself."""
     return 1 if world <= 1 else 2
+
+
+def headline_depth(world):
+    """Frames in flight on each of `world` GPUs for a frame of few launches (no secondary rays: bench.py's headline
+    workload).  The ends of its walk kernels are latency-bound, so even a whole frame gains from a second one beside it
+    (temple 4K, one GPU, one / two / three in flight: 2.14 / 1.80 / 1.82 ms per frame); an eighth of a frame is short
+    against those ends and against the exchange, and three hide more of them (one rank of eight, two / three in flight:
+    0.57 / 0.47 ms; of four: 0.72 / 0.77; of two: 1.19 / 1.19; with a hardware queue for every stream, GPU_MAX_HW_QUEUES=16)."""
+    return 3 if world >= 8 else 2
 
 
 class FramePipeline:
@@ -188,7 +195,12 @@ class FramePipeline:
     frames, and with them the collectives, in the same order; the collectives of one frame wait for that frame's kernels
     only, so the next frame's kernels run beside them.
 
-    make_renderer() returns a fresh Renderer on this rank's device for every slot."""
+    make_renderer() returns a fresh Renderer on this rank's device for every slot.
+
+    Streams and hardware queues: every slot keeps two streams busy (its own and the one its context sets the next frame up
+    on).  HIP shares a few hardware queues among a process's streams (GPU_MAX_HW_QUEUES, four by default) and streams on
+    one queue run one after the other, so a process that keeps frames in flight should start with GPU_MAX_HW_QUEUES=16
+    in its environment (before its first HIP call; bench.py does: temple 4K two in flight 1.96 -> 1.80 ms per frame)."""
 
     def __init__(self, make_renderer, scene, rank=0, world=1, depth=None, group=None):
         depth = default_depth(world) if depth is None else int(depth)

@@ -37,15 +37,16 @@ for prefix, w, h in (("scenes/s3/s3", 96, 72), ("scenes/s2/s2", 64, 48), ("scene
     want = r2.tonemap_host(g["rgb"], g["minmax"], scene.gamma)
     assert np.array_equal(got, want), prefix
     assert np.array_equal(fr.global_minmax.cpu().numpy(), g["minmax"]), prefix
-    # the same frames two deep: each slot of the pipeline has its own context and stream, the collectives of one frame are
-    # issued between the kernels of the other
-    pipe = D.FramePipeline(lambda: rt.Renderer(0), scene, 0, 1, depth=2)
-    imgs = [pipe.frame() for _ in range(5)]
-    pipe.finish()
-    torch.cuda.synchronize()
-    for img, _ in imgs[-2:]:
-        assert np.array_equal(img.cpu().numpy().view(np.uint32).reshape(h, w), want), prefix
-    pipe.close()
+    # the same frames two and three deep (what bench.py runs on up to four, and on eight GPUs): each slot of the pipeline has
+    # its own context and stream, the collectives of one frame are issued between the kernels of the others
+    for depth in (2, 3):
+        pipe = D.FramePipeline(lambda: rt.Renderer(0), scene, 0, 1, depth=depth)
+        imgs = [pipe.frame() for _ in range(2 * depth + 1)]
+        pipe.finish()
+        torch.cuda.synchronize()
+        for img, _ in imgs[-depth:]:
+            assert np.array_equal(img.cpu().numpy().view(np.uint32).reshape(h, w), want), (prefix, depth)
+        pipe.close()
     r.close(); r2.close()
 dist.destroy_process_group()
 print("rccl single rank ok")
@@ -59,7 +60,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_frame_loop_with_collectives_issued_to_rccl():
+@pytest.mark.parametrize("queues", ["", "16"])
+def test_frame_loop_with_collectives_issued_to_rccl(queues):
+    """queues: GPU_MAX_HW_QUEUES as the box has it, and 16 as bench.py sets it for its ranks."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if queues:
+        env["GPU_MAX_HW_QUEUES"] = queues
     p = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0 and "rccl single rank ok" in p.stdout, (p.stdout[-800:], p.stderr[-1500:])
