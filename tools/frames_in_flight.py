@@ -49,7 +49,8 @@ def run(wd, k, mode, wpc=0):
             rgb, ids, mm, rgba, n = bufs[i]
             if mode == "stagger" and f > 0 and k > 1:
                 s.wait_event(evs[(f - 1) % k])
-            r.frame_begin()
+            if f < k or os.environ.get("RT_SKIP_SETUP") != "1":  # (RT_SKIP_SETUP=1: the frames after the first reuse its grid and lists: what the set-up costs)
+                r.frame_begin()
             if mode == "stagger":
                 r.render_trace(0, wd)
                 evs[i].record(s)
